@@ -1,0 +1,164 @@
+/*
+ * srz.h — C ABI of the MI355X-native triangle rasterization + fragment-shading stage.
+ *
+ * This is the drop-in boundary for ONE path of Liupeter01/Software-Rasterizer:
+ *     virtual void RenderingPipeline::draw(Primitive) = 0        (include/base/Render.hpp:84)
+ *     void TraditionalRasterizer::draw(Primitive)                (src/Rasterizer.cpp:183-240)
+ * The reference has no FFI; the seam is that C++ virtual.  Everything `draw` pulls from the
+ * scene (post-MVP triangle stream, lights, eye, shader type, texture, Blinn-Phong constants)
+ * is passed here as plain pointers and sizes; everything it writes (z-buffer + 3 planar float
+ * colour planes, include/base/Render.hpp:250-257) comes back through plain pointers.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, negative SRZ_E_* on error; text via srz_last_error().
+ *   - no exception crosses this boundary; the C++ host shim (software-rasterizer_amd/host)
+ *     rethrows as std::runtime_error for draw() to keep the reference's convention
+ *     (src/Rasterizer.cpp:185-189).
+ *   - the caller owns every host pointer; the library copies in/out and keeps only device state.
+ *   - one ctx per host thread, one GPU per ctx, one process per GPU (multi-GPU = one ctx per rank,
+ *     bands of 32 rows dealt round-robin with srz_set_shard, reassembled by an RCCL all-gather).
+ *   - there is NO CPU fallback: every compute entry point fails with SRZ_E_NODEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef SRZ_H_
+#define SRZ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRZ_ABI_VERSION 1
+
+/* error codes */
+#define SRZ_OK 0
+#define SRZ_E_INVALID (-1)  /* bad argument (null pointer, bad size, unknown shader, ...) */
+#define SRZ_E_NODEVICE (-2) /* no usable HIP device / HIP runtime error */
+#define SRZ_E_NOMEM (-3)    /* host or device allocation failed */
+#define SRZ_E_TEXTURE (-4)  /* a TEXTURE/BUMP/DISPLACEMENT batch names a tex_id that was not uploaded */
+#define SRZ_E_PRIMITIVE (-5) /* primitive type not supported (src/Rasterizer.cpp:185-189) */
+
+/* = SoftRasterizer::SHADERS_TYPE (include/shader/Shader.hpp:32-38) */
+#define SRZ_SHADER_NORMAL 0
+#define SRZ_SHADER_TEXTURE 1
+#define SRZ_SHADER_PHONG 2
+#define SRZ_SHADER_DISPLACEMENT 3
+#define SRZ_SHADER_BUMP 4
+
+/* = SoftRasterizer::Primitive (include/base/Render.hpp:74) */
+#define SRZ_PRIMITIVE_LINES 0
+#define SRZ_PRIMITIVE_TRIANGLES 1
+
+/* frame flags */
+#define SRZ_EXACT_SPLIT 0u /* default: reproduce the reference's AVX-columns / scalar-tail split per (triangle,pixel) */
+#define SRZ_UNIFIED 1u     /* every pixel uses the 8-wide ("AVX") semantics; NOT reference-exact, for A/B only */
+#define SRZ_FUSED_CLEAR 2u /* treat z/colour as just cleared (clear(Color|Depth), src/Render.cpp:46-55): write-only framebuffer */
+
+/* Post-MVP triangle = payload of SoftRasterizer::Triangle that draw() consumes
+ * (m_vertex/m_normal/m_texCoords, include/object/Triangle.hpp:88-93).  Screen-space x,y in pixels,
+ * z remapped to [near,far] (src/Scene.cpp:937-947).  bbox, cull and binning are recomputed on device. */
+typedef struct srz_tri {
+  float pos[3][3];
+  float nrm[3][3];
+  float uv[3][2];
+} srz_tri; /* 96 B */
+
+/* = light_struct {position,intensity} (include/light/Light.hpp:8-45) */
+typedef struct srz_light {
+  float pos[3];
+  float intensity[3];
+} srz_light; /* 24 B */
+
+/* One mesh's triangles with the shader bound to that mesh = one ObjTuple of
+ * Scene::loadTriangleStream (include/scene/Scene.hpp:30-31). Batches are drawn in array order,
+ * triangles in array order (src/Rasterizer.cpp:199-200). */
+typedef struct srz_batch {
+  int32_t shader;  /* SRZ_SHADER_* */
+  int32_t tex_id;  /* texture slot (srz_texture_upload); ignored by NORMAL / PHONG */
+  uint32_t n_tris;
+  uint32_t _pad;
+  const srz_tri *tris; /* host pointer, n_tris entries */
+} srz_batch;
+
+/* Everything one draw() of one scene pulls (src/Rasterizer.cpp:191-196) */
+typedef struct srz_frame {
+  int32_t width, height; /* RenderingPipeline::m_width/m_height */
+  float eye[3];          /* Scene::loadEyeVec() (camera POSITION) */
+  float ka[3], ks[3];    /* Shader::ka / ks statics (src/Shader.cpp:7-8) */
+  float p;               /* Shader::p (src/Shader.cpp:10) */
+  float kh, kn;          /* Shader::kh / kn (src/Shader.cpp:11-12), BUMP / DISPLACEMENT only */
+  uint32_t n_lights;
+  uint32_t n_batches;
+  const srz_light *lights;
+  const srz_batch *batches;
+  uint32_t flags; /* SRZ_EXACT_SPLIT | SRZ_UNIFIED | SRZ_FUSED_CLEAR */
+  uint32_t _pad;
+} srz_frame;
+
+/* Per-call counters (summed over the frames of the call). */
+typedef struct srz_stats {
+  uint64_t n_tris;      /* triangles submitted */
+  uint64_t n_culled;    /* rejected by the backface test (src/Rasterizer.cpp:203-205) */
+  uint64_t pixel_tests; /* sum of bbox areas of the surviving triangles */
+  uint64_t fragments;   /* (triangle,pixel) pairs that pass the coverage test */
+  uint64_t shaded;      /* of those, pairs that also pass the z-test in submission order */
+  uint64_t visible;     /* pixels whose final owner is a triangle of this call */
+  uint64_t visible_textured; /* of those, pixels whose owner's shader fetches the texture (B_tex of the roofline) */
+} srz_stats;
+
+typedef struct srz_ctx srz_ctx;
+typedef struct srz_frameset srz_frameset;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int srz_abi_version(void);
+/* device_id: HIP ordinal. Replaces the TraditionalRasterizer(w,h) construction of device state. */
+int srz_create(srz_ctx **out, int device_id);
+void srz_destroy(srz_ctx *ctx);
+const char *srz_last_error(const srz_ctx *ctx); /* ctx may be NULL: last error of srz_create */
+
+/* Multi-GPU: this ctx owns the 32-row bands b with b % world == rank (local band b / world).
+ * Default (0,1) = whole frame. Affects srz_frameset_* only. */
+int srz_set_shard(srz_ctx *ctx, int rank, int world);
+
+/* ---- texture = TextureLoader's cv::Mat (BGR u8, row-major, top row first;
+ *      src/TextureLoader.cpp:3-12).  row_stride in bytes. Slots 0..63. ------------------- */
+int srz_texture_upload(srz_ctx *ctx, int tex_id, const uint8_t *bgr, int w, int h, int row_stride);
+
+/* ---- draw = TraditionalRasterizer::draw(TRIANGLES) for one scene ----------------------
+ * z/c0/c1/c2: W*H floats each, in/out (m_zBuffer, m_channels[0..2]); draw never clears unless
+ * SRZ_FUSED_CLEAR.  primitive: LINES is accepted and rasterised as triangles exactly like the
+ * reference (src/Rasterizer.cpp:185-189; rasterizeWireframe is never called); anything else →
+ * SRZ_E_PRIMITIVE.  stats may be NULL. */
+int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, float *c0, float *c1,
+             float *c2, srz_stats *stats);
+
+/* ---- throughput mode: frames resident in HBM ------------------------------------------
+ * A frameset copies n frames (same width/height) to the device once.  srz_frameset_render
+ * rasterises + shades all of them into ONE device buffer laid out
+ *     [frame][plane: z,c0,c1,c2][local_rows][width]   (float32)
+ * where local_rows = srz_frameset_local_rows() (= height for an unsharded ctx, else
+ * bands_per_rank*32, zero-padded).  d_out is a DEVICE pointer (e.g. a torch tensor's data_ptr),
+ * stream a hipStream_t (NULL = the ctx's own stream).  The call is asynchronous on that stream. */
+int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out);
+void srz_frameset_destroy(srz_ctx *ctx, srz_frameset *fs);
+int srz_frameset_local_rows(const srz_ctx *ctx, const srz_frameset *fs);
+size_t srz_frameset_out_bytes(const srz_ctx *ctx, const srz_frameset *fs);
+int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_bytes,
+                        uint32_t flags, void *stream);
+/* synchronous: runs the counting variant of the kernels once and returns the counters */
+int srz_frameset_stats(srz_ctx *ctx, srz_frameset *fs, srz_stats *stats);
+/* Algorithmic bytes of one render of the frameset on this ctx (SURVEY §8d / DESIGN.md):
+ * 16*W*local_rows + 96*N_tri + 24*N_lights + B_tex per frame. n_shaded_tex = texture-shaded pixels. */
+uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *fs);
+/* Average device time (ms) of the dominant (raster+shade) kernel over the launches issued since
+ * the last call with reset!=0, measured with hipEvents on the launch stream. */
+int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *raster_ms, double *total_ms, int *launches);
+int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
+int srz_sync(srz_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRZ_H_ */

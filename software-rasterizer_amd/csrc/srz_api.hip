@@ -1,0 +1,501 @@
+// srz_api.hip — the C ABI declared in include/srz.h (host side: contexts, framesets, uploads, launches).
+// No CPU fallback exists: without a usable gfx950 device every compute entry point returns SRZ_E_NODEVICE.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "srz_device.h"
+
+using namespace srz;
+
+namespace {
+std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t t0, t1, t2, t3; // t0..t1 setup+bands, t2..t3 raster (t0..t3 total)
+};
+} // namespace
+
+struct srz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int shard_rank = 0, shard_world = 1;
+  TexDesc h_tex[MAX_TEX];
+  uint32_t *d_texmem[MAX_TEX];
+  TexDesc *d_tex = nullptr;
+  unsigned long long *d_stats = nullptr;
+  bool timing = false;
+  std::vector<EventPair> ev_pool, ev_used;
+  double acc_raster_ms = 0.0, acc_total_ms = 0.0;
+  int acc_launches = 0;
+};
+
+struct srz_frameset {
+  int n_frames = 0, width = 0, height = 0;
+  int shard_rank = 0, shard_world = 1;
+  uint32_t n_bands = 0, n_local_bands = 0, bands_per_rank = 0, local_rows = 0;
+  uint32_t max_tris = 0;
+  uint64_t total_tris = 0, total_lights = 0;
+  std::vector<FrameDesc> h_frames;
+  std::vector<BatchDesc> h_batches;
+  FrameDesc *d_frames = nullptr;
+  srz_tri *d_tris = nullptr;
+  BBox *d_bbox = nullptr;
+  uint16_t *d_tri_batch = nullptr;
+  BatchDesc *d_batches = nullptr;
+  srz_light *d_lights = nullptr;
+  uint32_t *d_band_lists = nullptr;
+  uint32_t *d_band_count = nullptr;
+  bool have_stats = false;
+  srz_stats stats{};
+};
+
+namespace {
+
+int fail(srz_ctx *ctx, int code, const std::string &msg) {
+  if (ctx)
+    ctx->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                             \
+  do {                                                                                                                 \
+    hipError_t e_ = (expr);                                                                                            \
+    if (e_ != hipSuccess)                                                                                              \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? SRZ_E_NOMEM : SRZ_E_NODEVICE,                                      \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                                  \
+  } while (0)
+
+void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &n_local, uint32_t &per_rank,
+                  uint32_t &local_rows) {
+  n_bands = (uint32_t)((height + BAND - 1) / BAND);
+  n_local = (uint32_t)rank < n_bands ? (n_bands - (uint32_t)rank + (uint32_t)world - 1) / (uint32_t)world : 0;
+  per_rank = (n_bands + (uint32_t)world - 1) / (uint32_t)world;
+  local_rows = world == 1 ? (uint32_t)height : per_rank * BAND;
+}
+
+void free_frameset_buffers(srz_frameset *fs) {
+  (void)hipFree(fs->d_frames);
+  (void)hipFree(fs->d_tris);
+  (void)hipFree(fs->d_bbox);
+  (void)hipFree(fs->d_tri_batch);
+  (void)hipFree(fs->d_batches);
+  (void)hipFree(fs->d_lights);
+  (void)hipFree(fs->d_band_lists);
+  (void)hipFree(fs->d_band_count);
+}
+
+RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, uint32_t flags_or) {
+  RenderArgs a{};
+  a.frames = fs->d_frames;
+  a.tris = fs->d_tris;
+  a.bbox = fs->d_bbox;
+  a.tri_batch = fs->d_tri_batch;
+  a.batches = fs->d_batches;
+  a.lights = fs->d_lights;
+  a.tex = ctx->d_tex;
+  a.band_lists = fs->d_band_lists;
+  a.band_count = fs->d_band_count;
+  a.out = d_out;
+  a.local_rows = fs->local_rows;
+  a.frame_stride = 4ull * fs->local_rows * (uint64_t)fs->width;
+  a.shard_rank = fs->shard_rank;
+  a.shard_world = fs->shard_world;
+  a.flags_or = flags_or;
+  a.stats = ctx->d_stats;
+  return a;
+}
+
+int get_events(srz_ctx *ctx, EventPair &ep) {
+  if (!ctx->ev_pool.empty()) {
+    ep = ctx->ev_pool.back();
+    ctx->ev_pool.pop_back();
+    return SRZ_OK;
+  }
+  HIP_TRY(ctx, hipEventCreate(&ep.t0));
+  HIP_TRY(ctx, hipEventCreate(&ep.t1));
+  HIP_TRY(ctx, hipEventCreate(&ep.t2));
+  HIP_TRY(ctx, hipEventCreate(&ep.t3));
+  return SRZ_OK;
+}
+
+int collect_events(srz_ctx *ctx) {
+  for (auto &ep : ctx->ev_used) {
+    HIP_TRY(ctx, hipEventSynchronize(ep.t3));
+    float r = 0.f, t = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&r, ep.t2, ep.t3));
+    HIP_TRY(ctx, hipEventElapsedTime(&t, ep.t0, ep.t3));
+    ctx->acc_raster_ms += r;
+    ctx->acc_total_ms += t;
+    ctx->acc_launches++;
+    ctx->ev_pool.push_back(ep);
+  }
+  ctx->ev_used.clear();
+  return SRZ_OK;
+}
+
+// setup → bands → raster for every frame of the set, asynchronously on `s`
+int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or, hipStream_t s, bool stats) {
+  if (fs->shard_rank != ctx->shard_rank || fs->shard_world != ctx->shard_world)
+    return fail(ctx, SRZ_E_INVALID, "frameset was created under a different shard (call srz_set_shard before srz_frameset_create)");
+  for (const BatchDesc &b : fs->h_batches) {
+    bool needs = b.shader == SRZ_SHADER_TEXTURE || b.shader == SRZ_SHADER_DISPLACEMENT || b.shader == SRZ_SHADER_BUMP;
+    if (needs && (b.tex_id < 0 || b.tex_id >= MAX_TEX || !ctx->h_tex[b.tex_id].bgrx))
+      return fail(ctx, SRZ_E_TEXTURE, "batch uses texture slot " + std::to_string(b.tex_id) + " which was never uploaded");
+  }
+  RenderArgs a = make_args(ctx, fs, d_out, flags_or);
+  EventPair ep{};
+  bool timed = ctx->timing && !stats && ctx->ev_used.size() < 65536;
+  if (timed) {
+    int rc = get_events(ctx, ep);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ep.t0, s));
+  }
+  if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
+  launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
+  launch_bands(a, fs->d_band_lists, fs->d_band_count, fs->n_frames, fs->n_local_bands, s);
+  if (timed) {
+    HIP_TRY(ctx, hipEventRecord(ep.t1, s));
+    HIP_TRY(ctx, hipEventRecord(ep.t2, s));
+  }
+  launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
+  if (timed) {
+    HIP_TRY(ctx, hipEventRecord(ep.t3, s));
+    ctx->ev_used.push_back(ep);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return SRZ_OK;
+}
+
+int read_stats(srz_ctx *ctx, hipStream_t s, srz_stats *st) {
+  unsigned long long h[ST_COUNT];
+  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  st->n_tris = h[ST_TRIS], st->n_culled = h[ST_CULLED], st->pixel_tests = h[ST_PIXEL_TESTS];
+  st->fragments = h[ST_FRAGMENTS], st->shaded = h[ST_SHADED], st->visible = h[ST_VISIBLE];
+  st->visible_textured = h[ST_VISIBLE_TEX];
+  return SRZ_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int srz_abi_version(void) { return SRZ_ABI_VERSION; }
+
+int srz_create(srz_ctx **out, int device_id) {
+  if (!out) return fail(nullptr, SRZ_E_INVALID, "srz_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, SRZ_E_NODEVICE,
+                std::string("srz_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                    "); this library has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, SRZ_E_INVALID, "srz_create: device_id out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+    return fail(nullptr, SRZ_E_NODEVICE, "srz_create: hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, SRZ_E_NODEVICE, std::string("srz_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  srz_ctx *ctx = new (std::nothrow) srz_ctx();
+  if (!ctx) return fail(nullptr, SRZ_E_NOMEM, "srz_create: out of host memory");
+  ctx->device = device_id;
+  for (int i = 0; i < MAX_TEX; ++i) ctx->h_tex[i] = TexDesc{nullptr, 0, 0}, ctx->d_texmem[i] = nullptr;
+  auto bail = [&](const char *what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    (void)hipFree(ctx->d_tex);
+    (void)hipFree(ctx->d_stats);
+    delete ctx;
+    return SRZ_E_NODEVICE;
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipMalloc(&ctx->d_tex, sizeof(TexDesc) * MAX_TEX)) != hipSuccess) return bail("hipMalloc(tex table)", e);
+  if ((e = hipMemset(ctx->d_tex, 0, sizeof(TexDesc) * MAX_TEX)) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * ST_COUNT)) != hipSuccess) return bail("hipMalloc(stats)", e);
+  *out = ctx;
+  return SRZ_OK;
+}
+
+void srz_destroy(srz_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &ep : ctx->ev_used) ctx->ev_pool.push_back(ep);
+  for (auto &ep : ctx->ev_pool) (void)hipEventDestroy(ep.t0), (void)hipEventDestroy(ep.t1), (void)hipEventDestroy(ep.t2), (void)hipEventDestroy(ep.t3);
+  for (int i = 0; i < MAX_TEX; ++i) (void)hipFree(ctx->d_texmem[i]);
+  (void)hipFree(ctx->d_tex);
+  (void)hipFree(ctx->d_stats);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *srz_last_error(const srz_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int srz_set_shard(srz_ctx *ctx, int rank, int world) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, SRZ_E_INVALID, "srz_set_shard: need 0 <= rank < world");
+  ctx->shard_rank = rank, ctx->shard_world = world;
+  return SRZ_OK;
+}
+
+int srz_texture_upload(srz_ctx *ctx, int tex_id, const uint8_t *bgr, int w, int h, int row_stride) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (tex_id < 0 || tex_id >= MAX_TEX || !bgr || w <= 0 || h <= 0 || row_stride < 3 * w || w > 32768 || h > 32768)
+    return fail(ctx, SRZ_E_INVALID, "srz_texture_upload: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t *d_raw = nullptr;
+  uint32_t *d_px = nullptr;
+  size_t raw = (size_t)row_stride * h;
+  HIP_TRY(ctx, hipMalloc(&d_raw, raw));
+  hipError_t e = hipMalloc(&d_px, (size_t)w * h * 4);
+  if (e != hipSuccess) {
+    (void)hipFree(d_raw);
+    return fail(ctx, SRZ_E_NOMEM, "srz_texture_upload: hipMalloc failed");
+  }
+  e = hipMemcpyAsync(d_raw, bgr, raw, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_tex_convert(d_raw, w, h, row_stride, d_px, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(d_raw);
+  if (e != hipSuccess) {
+    (void)hipFree(d_px);
+    return fail(ctx, SRZ_E_NODEVICE, std::string("srz_texture_upload: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(ctx->d_texmem[tex_id]);
+  ctx->d_texmem[tex_id] = d_px;
+  ctx->h_tex[tex_id] = TexDesc{d_px, w, h};
+  HIP_TRY(ctx, hipMemcpy(ctx->d_tex + tex_id, &ctx->h_tex[tex_id], sizeof(TexDesc), hipMemcpyHostToDevice));
+  return SRZ_OK;
+}
+
+int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!out) return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: out is NULL");
+  *out = nullptr;
+  if (!frames || n_frames <= 0) return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: no frames");
+  const int W = frames[0].width, H = frames[0].height;
+  if (W <= 0 || H <= 0 || W > 32767 || H > 32767) return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: width/height must be in 1..32767");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  srz_frameset *fs = new (std::nothrow) srz_frameset();
+  if (!fs) return fail(ctx, SRZ_E_NOMEM, "srz_frameset_create: out of host memory");
+  fs->n_frames = n_frames, fs->width = W, fs->height = H;
+  fs->shard_rank = ctx->shard_rank, fs->shard_world = ctx->shard_world;
+  shard_layout(H, fs->shard_rank, fs->shard_world, fs->n_bands, fs->n_local_bands, fs->bands_per_rank, fs->local_rows);
+  uint64_t tri_off = 0, light_off = 0, batch_off = 0, list_off = 0, count_off = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const srz_frame &fr = frames[f];
+    auto bad = [&](const char *m) {
+      delete fs;
+      return fail(ctx, SRZ_E_INVALID, std::string("srz_frameset_create: frame ") + std::to_string(f) + ": " + m);
+    };
+    if (fr.width != W || fr.height != H) return bad("all frames of a set must share width/height");
+    if ((fr.n_lights && !fr.lights) || (fr.n_batches && !fr.batches)) return bad("null lights/batches");
+    if (fr.n_batches > 65535) return bad("more than 65535 batches");
+    FrameDesc d{};
+    d.width = W, d.height = H;
+    std::memcpy(d.eye, fr.eye, sizeof d.eye);
+    std::memcpy(d.ka, fr.ka, sizeof d.ka);
+    std::memcpy(d.ks, fr.ks, sizeof d.ks);
+    d.p = fr.p, d.kh = fr.kh, d.kn = fr.kn;
+    d.n_lights = fr.n_lights, d.light_off = (uint32_t)light_off;
+    d.tri_off = (uint32_t)tri_off, d.n_batches = fr.n_batches, d.batch_off = (uint32_t)batch_off;
+    d.flags = fr.flags;
+    uint64_t nt = 0;
+    for (uint32_t b = 0; b < fr.n_batches; ++b) {
+      const srz_batch &sb = fr.batches[b];
+      if (sb.n_tris && !sb.tris) return bad("batch with null triangle pointer");
+      if (sb.shader < SRZ_SHADER_NORMAL || sb.shader > SRZ_SHADER_BUMP) return bad("unknown shader type");
+      fs->h_batches.push_back(BatchDesc{sb.shader, sb.tex_id, (uint32_t)nt, sb.n_tris});
+      nt += sb.n_tris;
+    }
+    if (tri_off + nt > 0xfffffff0ull) return bad("too many triangles");
+    d.n_tris = (uint32_t)nt;
+    d.n_local_bands = fs->n_local_bands;
+    d.list_off = list_off, d.count_off = (uint32_t)count_off;
+    fs->h_frames.push_back(d);
+    fs->max_tris = std::max(fs->max_tris, d.n_tris);
+    tri_off += nt, light_off += fr.n_lights, batch_off += fr.n_batches;
+    list_off += (uint64_t)fs->n_local_bands * nt, count_off += fs->n_local_bands;
+  }
+  fs->total_tris = tri_off, fs->total_lights = light_off;
+
+  // stage host copies (pinned not needed: one-time upload)
+  std::vector<srz_tri> h_tris((size_t)tri_off);
+  std::vector<uint16_t> h_tb((size_t)tri_off);
+  std::vector<srz_light> h_lights((size_t)light_off);
+  for (int f = 0; f < n_frames; ++f) {
+    const srz_frame &fr = frames[f];
+    const FrameDesc &d = fs->h_frames[f];
+    size_t o = d.tri_off;
+    for (uint32_t b = 0; b < fr.n_batches; ++b) {
+      const srz_batch &sb = fr.batches[b];
+      if (sb.n_tris) std::memcpy(&h_tris[o], sb.tris, sizeof(srz_tri) * sb.n_tris);
+      std::fill(h_tb.begin() + o, h_tb.begin() + o + sb.n_tris, (uint16_t)b);
+      o += sb.n_tris;
+    }
+    if (fr.n_lights) std::memcpy(&h_lights[d.light_off], fr.lights, sizeof(srz_light) * fr.n_lights);
+  }
+  auto dev_alloc = [&](void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 256)); };
+  hipError_t e = hipSuccess;
+#define FS_TRY(expr)                                                                                                   \
+  if (e == hipSuccess) e = (expr)
+  FS_TRY(dev_alloc((void **)&fs->d_frames, sizeof(FrameDesc) * n_frames));
+  FS_TRY(dev_alloc((void **)&fs->d_tris, sizeof(srz_tri) * tri_off));
+  FS_TRY(dev_alloc((void **)&fs->d_bbox, sizeof(BBox) * tri_off));
+  FS_TRY(dev_alloc((void **)&fs->d_tri_batch, sizeof(uint16_t) * tri_off));
+  FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
+  FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));
+  FS_TRY(dev_alloc((void **)&fs->d_band_lists, sizeof(uint32_t) * list_off));
+  FS_TRY(dev_alloc((void **)&fs->d_band_count, sizeof(uint32_t) * count_off));
+  FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
+  if (tri_off) {
+    FS_TRY(hipMemcpy(fs->d_tris, h_tris.data(), sizeof(srz_tri) * tri_off, hipMemcpyHostToDevice));
+    FS_TRY(hipMemcpy(fs->d_tri_batch, h_tb.data(), sizeof(uint16_t) * tri_off, hipMemcpyHostToDevice));
+  }
+  if (!fs->h_batches.empty())
+    FS_TRY(hipMemcpy(fs->d_batches, fs->h_batches.data(), sizeof(BatchDesc) * fs->h_batches.size(), hipMemcpyHostToDevice));
+  if (light_off) FS_TRY(hipMemcpy(fs->d_lights, h_lights.data(), sizeof(srz_light) * light_off, hipMemcpyHostToDevice));
+#undef FS_TRY
+  if (e != hipSuccess) {
+    free_frameset_buffers(fs);
+    delete fs;
+    return fail(ctx, e == hipErrorOutOfMemory ? SRZ_E_NOMEM : SRZ_E_NODEVICE,
+                std::string("srz_frameset_create: ") + hipGetErrorString(e));
+  }
+  *out = fs;
+  return SRZ_OK;
+}
+
+void srz_frameset_destroy(srz_ctx *ctx, srz_frameset *fs) {
+  if (!fs) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  free_frameset_buffers(fs);
+  delete fs;
+}
+
+int srz_frameset_local_rows(const srz_ctx *ctx, const srz_frameset *fs) { return fs ? (int)fs->local_rows : SRZ_E_INVALID; }
+
+size_t srz_frameset_out_bytes(const srz_ctx *ctx, const srz_frameset *fs) {
+  return fs ? (size_t)fs->n_frames * 4u * fs->local_rows * (size_t)fs->width * sizeof(float) : 0;
+}
+
+int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_bytes, uint32_t flags, void *stream) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!fs || !d_out) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: null frameset / output");
+  if (out_bytes < srz_frameset_out_bytes(ctx, fs)) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: output buffer too small");
+  if (((uintptr_t)d_out & 15u) != 0) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: output must be 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return render_impl(ctx, fs, (float *)d_out, flags, s, false);
+}
+
+int srz_frameset_stats(srz_ctx *ctx, srz_frameset *fs, srz_stats *stats) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!fs || !stats) return fail(ctx, SRZ_E_INVALID, "srz_frameset_stats: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  float *d_out = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_out, srz_frameset_out_bytes(ctx, fs)));
+  int rc = render_impl(ctx, fs, d_out, SRZ_FUSED_CLEAR, ctx->stream, true);
+  if (rc == SRZ_OK) rc = read_stats(ctx, ctx->stream, stats);
+  (void)hipFree(d_out);
+  if (rc == SRZ_OK) fs->stats = *stats, fs->have_stats = true;
+  return rc;
+}
+
+uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *fs) {
+  if (!ctx || !fs) return 0;
+  // rows actually owned (not the all-gather padding)
+  uint64_t rows = 0;
+  for (uint32_t lb = 0; lb < fs->n_local_bands; ++lb) {
+    int band = (int)lb * fs->shard_world + fs->shard_rank;
+    rows += (uint64_t)std::min(BAND, fs->height - band * BAND);
+  }
+  uint64_t fb = 16ull * (uint64_t)fs->width * rows * (uint64_t)fs->n_frames;
+  uint64_t stream = 96ull * fs->total_tris + 24ull * fs->total_lights;
+  uint64_t tex = 0;
+  if (fs->have_stats) {
+    // B_tex = min(3*texW*texH per frame, 3 bytes per texture-shaded pixel)
+    uint64_t cap = 0;
+    for (const BatchDesc &b : fs->h_batches)
+      if (b.tex_id >= 0 && b.tex_id < MAX_TEX && ctx->h_tex[b.tex_id].bgrx &&
+          (b.shader == SRZ_SHADER_TEXTURE || b.shader == SRZ_SHADER_DISPLACEMENT || b.shader == SRZ_SHADER_BUMP))
+        cap = std::max<uint64_t>(cap, 3ull * ctx->h_tex[b.tex_id].w * ctx->h_tex[b.tex_id].h);
+    tex = std::min<uint64_t>(cap * (uint64_t)fs->n_frames, 3ull * fs->stats.visible_textured);
+  }
+  return fb + stream + tex;
+}
+
+int srz_set_kernel_timing(srz_ctx *ctx, int enabled) {
+  if (!ctx) return SRZ_E_INVALID;
+  ctx->timing = enabled != 0;
+  return SRZ_OK;
+}
+
+int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *raster_ms, double *total_ms, int *launches) {
+  if (!ctx) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = collect_events(ctx);
+  if (rc) return rc;
+  if (raster_ms) *raster_ms = ctx->acc_launches ? ctx->acc_raster_ms / ctx->acc_launches : 0.0;
+  if (total_ms) *total_ms = ctx->acc_launches ? ctx->acc_total_ms / ctx->acc_launches : 0.0;
+  if (launches) *launches = ctx->acc_launches;
+  if (reset) ctx->acc_raster_ms = ctx->acc_total_ms = 0.0, ctx->acc_launches = 0;
+  return SRZ_OK;
+}
+
+int srz_sync(srz_ctx *ctx) {
+  if (!ctx) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SRZ_OK;
+}
+
+int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, float *c0, float *c1, float *c2,
+             srz_stats *stats) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (primitive != SRZ_PRIMITIVE_LINES && primitive != SRZ_PRIMITIVE_TRIANGLES)
+    return fail(ctx, SRZ_E_PRIMITIVE, "Primitive Type is not supported!");
+  if (!frame || !z || !c0 || !c1 || !c2) return fail(ctx, SRZ_E_INVALID, "srz_draw: null argument");
+  if (ctx->shard_world != 1) return fail(ctx, SRZ_E_INVALID, "srz_draw: whole-frame draw needs an unsharded ctx (srz_set_shard(ctx,0,1))");
+  srz_frameset *fs = nullptr;
+  int rc = srz_frameset_create(ctx, frame, 1, &fs);
+  if (rc) return rc;
+  const size_t plane = (size_t)frame->width * frame->height, pb = plane * sizeof(float);
+  float *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_out, 4 * pb);
+  if (e != hipSuccess) {
+    srz_frameset_destroy(ctx, fs);
+    return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc failed");
+  }
+  hipStream_t s = ctx->stream;
+  const bool fused = (frame->flags & SRZ_FUSED_CLEAR) != 0;
+  float *host[4] = {z, c0, c1, c2};
+  if (!fused)
+    for (int p = 0; p < 4 && e == hipSuccess; ++p) e = hipMemcpyAsync(d_out + p * plane, host[p], pb, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = render_impl(ctx, fs, d_out, 0, s, stats != nullptr);
+    if (rc == SRZ_OK && stats) rc = read_stats(ctx, s, stats);
+  }
+  for (int p = 0; p < 4 && e == hipSuccess && rc == SRZ_OK; ++p)
+    e = hipMemcpyAsync(host[p], d_out + p * plane, pb, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_out);
+  srz_frameset_destroy(ctx, fs);
+  if (e != hipSuccess) return fail(ctx, SRZ_E_NODEVICE, std::string("srz_draw: ") + hipGetErrorString(e));
+  return rc;
+}
+
+} // extern "C"

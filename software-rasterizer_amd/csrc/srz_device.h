@@ -1,0 +1,77 @@
+// srz_device.h — device-side data layout shared by the kernels (srz_kernels.hip) and the C-ABI host code
+// (srz_api.hip).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srz.h"
+
+namespace srz {
+
+constexpr int TILE = 32;             // one wavefront owns one 32x32-pixel tile (its z + owner planes live in LDS)
+constexpr int BAND = 32;             // band = one row of tiles; the unit of multi-GPU sharding and of binning
+constexpr int WAVES_PER_WG = 4;      // a workgroup = 4 horizontally adjacent tiles = a 128x32 strip
+constexpr int LDS_STRIDE = 40;       // padded LDS row stride in dwords: 4 consecutive rows x 8 columns hit 32 distinct banks
+constexpr uint32_t NO_TRI = 0xffffffffu;
+constexpr int MAX_TEX = 64;
+
+// Screen-space bounding box of a surviving triangle (Triangle::calcBoundingBox, src/Triangle.cpp:243-257),
+// 8 bytes so that a wave scans 64 of them with one coalesced 512-B load. Culled / non-finite: sx > ex.
+struct __attribute__((aligned(8))) BBox {
+  int16_t sx, sy, ex, ey;
+};
+
+struct FrameDesc {
+  int32_t width, height;
+  float eye[3];
+  float ka[3];
+  float ks[3];
+  float p, kh, kn;
+  uint32_t n_lights, light_off;  // into lights[]
+  uint32_t n_tris, tri_off;      // into tris[] / bbox[] / tri_batch[]
+  uint32_t n_batches, batch_off; // into batches[]
+  uint32_t flags;
+  uint32_t n_local_bands;        // bands of this frame owned by this ctx
+  uint64_t list_off;             // into band_lists[] (entries): local band lb at list_off + lb * n_tris
+  uint32_t count_off;            // into band_count[]: local band lb at count_off + lb
+  uint32_t _pad;
+};
+
+struct BatchDesc {
+  int32_t shader, tex_id;
+  uint32_t first, count; // triangle range inside the frame
+};
+
+struct TexDesc {
+  const uint32_t *bgrx; // one dword per texel: B | G<<8 | R<<16
+  int32_t w, h;
+};
+
+// counters accumulated by the STATS kernel variants (same order as srz_stats)
+enum { ST_TRIS = 0, ST_CULLED, ST_PIXEL_TESTS, ST_FRAGMENTS, ST_SHADED, ST_VISIBLE, ST_VISIBLE_TEX, ST_COUNT };
+
+struct RenderArgs {
+  const FrameDesc *frames;
+  const srz_tri *tris;
+  const BBox *bbox;
+  const uint16_t *tri_batch;
+  const BatchDesc *batches;
+  const srz_light *lights;
+  const TexDesc *tex;
+  const uint32_t *band_lists;
+  const uint32_t *band_count;
+  float *out;             // [frame][4][local_rows][width]
+  uint64_t frame_stride;  // floats per frame in out = 4*local_rows*width
+  uint32_t local_rows;    // rows per plane in out
+  int32_t shard_rank, shard_world;
+  uint32_t flags_or;      // OR-ed into every frame's flags (SRZ_FUSED_CLEAR / SRZ_UNIFIED)
+  unsigned long long *stats;
+};
+
+void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
+void launch_bands(const RenderArgs &a, uint32_t *band_lists, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
+                  hipStream_t s);
+void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s);
+void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s);
+
+} // namespace srz

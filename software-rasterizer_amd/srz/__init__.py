@@ -1,0 +1,168 @@
+"""srz — Python binding (ctypes) of the C ABI in include/srz.h, the MI355X raster + fragment-shade stage.
+
+The compute path is ONLY libsrz.so (hand-written gfx950 kernels).  There is no CPU fallback: if the
+library is missing or no gfx950 device is present, every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .abi import Frame  # noqa: F401
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libsrz.so")
+_lib = None
+
+EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
+           "srz_draw", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
+           "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync"]
+
+
+class SrzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"srz error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libsrz.so (fails loudly if it was not built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found — the HIP extension is not built and there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        fp, vp = C.POINTER(C.c_float), C.c_void_p
+        L.srz_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.srz_destroy.argtypes = [vp]
+        L.srz_destroy.restype = None
+        L.srz_last_error.argtypes = [vp]
+        L.srz_last_error.restype = C.c_char_p
+        L.srz_set_shard.argtypes = [vp, C.c_int, C.c_int]
+        L.srz_texture_upload.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.srz_draw.argtypes = [vp, C.c_int, C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
+        L.srz_frameset_create.argtypes = [vp, C.POINTER(abi.SrzFrame), C.c_int, C.POINTER(vp)]
+        L.srz_frameset_destroy.argtypes = [vp, vp]
+        L.srz_frameset_destroy.restype = None
+        L.srz_frameset_local_rows.argtypes = [vp, vp]
+        L.srz_frameset_out_bytes.argtypes = [vp, vp]
+        L.srz_frameset_out_bytes.restype = C.c_size_t
+        L.srz_frameset_render.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint32, vp]
+        L.srz_frameset_stats.argtypes = [vp, vp, C.POINTER(abi.SrzStats)]
+        L.srz_frameset_algorithmic_bytes.argtypes = [vp, vp]
+        L.srz_frameset_algorithmic_bytes.restype = C.c_uint64
+        L.srz_kernel_time_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.srz_set_kernel_timing.argtypes = [vp, C.c_int]
+        L.srz_sync.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class FrameSet:
+    """Frames resident in HBM (srz_frameset_*)."""
+
+    def __init__(self, ctx, frames):
+        self.ctx, self.frames = ctx, list(frames)
+        self.h = C.c_void_p()
+        arr = abi.frames_array(self.frames)
+        ctx._check(lib().srz_frameset_create(ctx.h, arr, len(self.frames), C.byref(self.h)))
+        self.n_frames = len(self.frames)
+        self.width, self.height = self.frames[0].width, self.frames[0].height
+        self.local_rows = lib().srz_frameset_local_rows(ctx.h, self.h)
+        self.out_bytes = lib().srz_frameset_out_bytes(ctx.h, self.h)
+
+    @property
+    def out_shape(self):
+        return (self.n_frames, 4, self.local_rows, self.width)
+
+    def render(self, d_out_ptr, out_bytes, flags=abi.FUSED_CLEAR, stream=None):
+        """d_out_ptr: integer device address (e.g. torch_tensor.data_ptr()). Asynchronous."""
+        self.ctx._check(lib().srz_frameset_render(self.ctx.h, self.h, C.c_void_p(d_out_ptr), out_bytes, flags,
+                                                  C.c_void_p(stream) if stream else None))
+
+    def stats(self):
+        st = abi.SrzStats()
+        self.ctx._check(lib().srz_frameset_stats(self.ctx.h, self.h, C.byref(st)))
+        return st.as_dict()
+
+    def algorithmic_bytes(self):
+        return int(lib().srz_frameset_algorithmic_bytes(self.ctx.h, self.h))
+
+    def close(self):
+        if self.h:
+            lib().srz_frameset_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One ctx per process / GPU (srz_create)."""
+
+    def __init__(self, device_id=0, rank=0, world=1):
+        self.h = C.c_void_p()
+        rc = lib().srz_create(C.byref(self.h), device_id)
+        if rc != 0:
+            raise SrzError(rc, lib().srz_last_error(None).decode())
+        if world != 1:
+            self.set_shard(rank, world)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SrzError(rc, lib().srz_last_error(self.h).decode())
+
+    def set_shard(self, rank, world):
+        self._check(lib().srz_set_shard(self.h, rank, world))
+
+    def texture_upload(self, tex_id, bgr):
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, c = a.shape
+        assert c == 3
+        self._check(lib().srz_texture_upload(self.h, tex_id, a.ctypes.data, w, h, w * 3))
+
+    def draw(self, frame, planes=None, primitive=abi.PRIMITIVE_TRIANGLES, want_stats=False):
+        """TraditionalRasterizer::draw for one scene; planes (z,c0,c1,c2) are modified in place."""
+        if planes is None:
+            h, w = frame.height, frame.width
+            planes = (np.full((h, w), np.inf, np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32),
+                      np.zeros((h, w), np.float32))
+        z, c0, c1, c2 = planes
+        st = abi.SrzStats()
+        self._check(lib().srz_draw(self.h, primitive, C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2),
+                                   C.byref(st) if want_stats else None))
+        return planes, (st.as_dict() if want_stats else None)
+
+    def frameset(self, frames):
+        return FrameSet(self, frames)
+
+    def set_kernel_timing(self, on):
+        self._check(lib().srz_set_kernel_timing(self.h, 1 if on else 0))
+
+    def kernel_time_ms(self, reset=True):
+        r, t, n = C.c_double(), C.c_double(), C.c_int()
+        self._check(lib().srz_kernel_time_ms(self.h, 1 if reset else 0, C.byref(r), C.byref(t), C.byref(n)))
+        return r.value, t.value, n.value
+
+    def sync(self):
+        self._check(lib().srz_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib().srz_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
