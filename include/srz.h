@@ -152,11 +152,14 @@ int srz_frameset_stats(srz_ctx *ctx, srz_frameset *fs, srz_stats *stats);
 /* Algorithmic bytes of one render of the frameset on this ctx (SURVEY §8d / DESIGN.md):
  * 16*W*local_rows + 96*N_tri + 24*N_lights + B_tex per frame. n_shaded_tex = texture-shaded pixels. */
 uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *fs);
-/* Average device time (ms) of the dominant (raster+shade) kernel over the launches issued since
- * the last call with reset!=0, measured with hipEvents on the launch stream. */
-int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *raster_ms, double *total_ms, int *launches);
+/* Average device time (ms) per srz_frameset_render since the last call with reset!=0, measured with hipEvents on
+ * the launch stream: ms4[0] = setup+binning kernels, ms4[1] = raster kernel (visibility + fused clear: writes the
+ * framebuffer), ms4[2] = shade kernel, ms4[3] = whole pipeline. */
+int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches);
 int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
 int srz_sync(srz_ctx *ctx);
+/* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
+int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
 
 #ifdef __cplusplus
 }

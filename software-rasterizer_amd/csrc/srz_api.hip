@@ -15,7 +15,7 @@ namespace {
 std::string g_create_error;
 
 struct EventPair {
-  hipEvent_t t0, t1, t2, t3; // t0..t1 setup+bands, t2..t3 raster (t0..t3 total)
+  hipEvent_t t0, t1, t2, t3; // t0..t1 setup+bands, t1..t2 raster (visibility + clear), t2..t3 shade
 };
 } // namespace
 
@@ -30,8 +30,10 @@ struct srz_ctx {
   unsigned long long *d_stats = nullptr;
   bool timing = false;
   std::vector<EventPair> ev_pool, ev_used;
-  double acc_raster_ms = 0.0, acc_total_ms = 0.0;
+  double acc_ms[4] = {0, 0, 0, 0}; // bin, raster, shade, total
+  uint64_t tex_version = 1;
   int acc_launches = 0;
+  unsigned long long dbg[ST_COUNT] = {};
 };
 
 struct srz_frameset {
@@ -48,8 +50,12 @@ struct srz_frameset {
   uint16_t *d_tri_batch = nullptr;
   BatchDesc *d_batches = nullptr;
   srz_light *d_lights = nullptr;
-  uint32_t *d_band_lists = nullptr;
+  RasterRec *d_band_recs = nullptr;
   uint32_t *d_band_count = nullptr;
+  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr;
+  ShadeDescG *d_sdesc = nullptr;
+  uint64_t sdesc_version = 0;
+  uint32_t tiles_x = 0, max_tiles = 0;
   bool have_stats = false;
   srz_stats stats{};
 };
@@ -87,7 +93,11 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_tri_batch);
   (void)hipFree(fs->d_batches);
   (void)hipFree(fs->d_lights);
-  (void)hipFree(fs->d_band_lists);
+  (void)hipFree(fs->d_band_recs);
+  (void)hipFree(fs->d_vis);
+  (void)hipFree(fs->d_worklist);
+  (void)hipFree(fs->d_work_count);
+  (void)hipFree(fs->d_sdesc);
   (void)hipFree(fs->d_band_count);
 }
 
@@ -100,7 +110,13 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.batches = fs->d_batches;
   a.lights = fs->d_lights;
   a.tex = ctx->d_tex;
-  a.band_lists = fs->d_band_lists;
+  a.band_recs = fs->d_band_recs;
+  a.sdesc = fs->d_sdesc;
+  a.vis = fs->d_vis;
+  a.worklist = fs->d_worklist;
+  a.work_count = fs->d_work_count;
+  a.tiles_x = fs->tiles_x;
+  a.n_local_bands = fs->n_local_bands;
   a.band_count = fs->d_band_count;
   a.out = d_out;
   a.local_rows = fs->local_rows;
@@ -128,11 +144,12 @@ int get_events(srz_ctx *ctx, EventPair &ep) {
 int collect_events(srz_ctx *ctx) {
   for (auto &ep : ctx->ev_used) {
     HIP_TRY(ctx, hipEventSynchronize(ep.t3));
-    float r = 0.f, t = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&r, ep.t2, ep.t3));
+    float b = 0.f, r = 0.f, sh = 0.f, t = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&b, ep.t0, ep.t1));
+    HIP_TRY(ctx, hipEventElapsedTime(&r, ep.t1, ep.t2));
+    HIP_TRY(ctx, hipEventElapsedTime(&sh, ep.t2, ep.t3));
     HIP_TRY(ctx, hipEventElapsedTime(&t, ep.t0, ep.t3));
-    ctx->acc_raster_ms += r;
-    ctx->acc_total_ms += t;
+    ctx->acc_ms[0] += b, ctx->acc_ms[1] += r, ctx->acc_ms[2] += sh, ctx->acc_ms[3] += t;
     ctx->acc_launches++;
     ctx->ev_pool.push_back(ep);
   }
@@ -149,6 +166,18 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     if (needs && (b.tex_id < 0 || b.tex_id >= MAX_TEX || !ctx->h_tex[b.tex_id].bgrx))
       return fail(ctx, SRZ_E_TEXTURE, "batch uses texture slot " + std::to_string(b.tex_id) + " which was never uploaded");
   }
+  if (fs->sdesc_version != ctx->tex_version && !fs->h_batches.empty()) { // (re)resolve batch → shader/texture
+    std::vector<ShadeDescG> h(fs->h_batches.size());
+    for (size_t i = 0; i < h.size(); ++i) {
+      const BatchDesc &b = fs->h_batches[i];
+      bool needs = b.shader == SRZ_SHADER_TEXTURE || b.shader == SRZ_SHADER_DISPLACEMENT || b.shader == SRZ_SHADER_BUMP;
+      h[i].shader = b.shader, h[i]._pad = 0;
+      h[i].tw = needs ? ctx->h_tex[b.tex_id].w : 1, h[i].th = needs ? ctx->h_tex[b.tex_id].h : 1;
+      h[i].tex = needs ? ctx->h_tex[b.tex_id].bgrx : nullptr;
+    }
+    HIP_TRY(ctx, hipMemcpy(fs->d_sdesc, h.data(), sizeof(ShadeDescG) * h.size(), hipMemcpyHostToDevice));
+    fs->sdesc_version = ctx->tex_version;
+  }
   RenderArgs a = make_args(ctx, fs, d_out, flags_or);
   EventPair ep{};
   bool timed = ctx->timing && !stats && ctx->ev_used.size() < 65536;
@@ -158,13 +187,13 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipEventRecord(ep.t0, s));
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
+  HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t), s));
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
-  launch_bands(a, fs->d_band_lists, fs->d_band_count, fs->n_frames, fs->n_local_bands, s);
-  if (timed) {
-    HIP_TRY(ctx, hipEventRecord(ep.t1, s));
-    HIP_TRY(ctx, hipEventRecord(ep.t2, s));
-  }
+  launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, s);
+  if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
   launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
+  if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
+  launch_shade(a, fs->max_tiles, stats, s);
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -180,6 +209,7 @@ int read_stats(srz_ctx *ctx, hipStream_t s, srz_stats *st) {
   st->n_tris = h[ST_TRIS], st->n_culled = h[ST_CULLED], st->pixel_tests = h[ST_PIXEL_TESTS];
   st->fragments = h[ST_FRAGMENTS], st->shaded = h[ST_SHADED], st->visible = h[ST_VISIBLE];
   st->visible_textured = h[ST_VISIBLE_TEX];
+  std::memcpy(ctx->dbg, h, sizeof h);
   return SRZ_OK;
 }
 
@@ -274,6 +304,7 @@ int srz_texture_upload(srz_ctx *ctx, int tex_id, const uint8_t *bgr, int w, int 
   (void)hipFree(ctx->d_texmem[tex_id]);
   ctx->d_texmem[tex_id] = d_px;
   ctx->h_tex[tex_id] = TexDesc{d_px, w, h};
+  ctx->tex_version++;
   HIP_TRY(ctx, hipMemcpy(ctx->d_tex + tex_id, &ctx->h_tex[tex_id], sizeof(TexDesc), hipMemcpyHostToDevice));
   return SRZ_OK;
 }
@@ -355,7 +386,13 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
   FS_TRY(dev_alloc((void **)&fs->d_tri_batch, sizeof(uint16_t) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));
-  FS_TRY(dev_alloc((void **)&fs->d_band_lists, sizeof(uint32_t) * list_off));
+  fs->tiles_x = (uint32_t)((W + TILE - 1) / TILE);
+  fs->max_tiles = (uint32_t)n_frames * fs->n_local_bands * fs->tiles_x;
+  FS_TRY(dev_alloc((void **)&fs->d_band_recs, sizeof(RasterRec) * list_off));
+  FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
+  FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
+  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t)));
+  FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_band_count, sizeof(uint32_t) * count_off));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
   if (tri_off) {
@@ -444,16 +481,23 @@ int srz_set_kernel_timing(srz_ctx *ctx, int enabled) {
   return SRZ_OK;
 }
 
-int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *raster_ms, double *total_ms, int *launches) {
+int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches) {
   if (!ctx) return SRZ_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = collect_events(ctx);
   if (rc) return rc;
-  if (raster_ms) *raster_ms = ctx->acc_launches ? ctx->acc_raster_ms / ctx->acc_launches : 0.0;
-  if (total_ms) *total_ms = ctx->acc_launches ? ctx->acc_total_ms / ctx->acc_launches : 0.0;
+  for (int i = 0; i < 4; ++i)
+    if (ms4) ms4[i] = ctx->acc_launches ? ctx->acc_ms[i] / ctx->acc_launches : 0.0;
   if (launches) *launches = ctx->acc_launches;
-  if (reset) ctx->acc_raster_ms = ctx->acc_total_ms = 0.0, ctx->acc_launches = 0;
+  if (reset) ctx->acc_ms[0] = ctx->acc_ms[1] = ctx->acc_ms[2] = ctx->acc_ms[3] = 0.0, ctx->acc_launches = 0;
   return SRZ_OK;
+}
+
+/* diagnostic: raw counters of the last STATS run (incl. per-phase cycle sums); not part of the stable ABI */
+int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n) {
+  if (!ctx || !out) return SRZ_E_INVALID;
+  for (int i = 0; i < n && i < ST_COUNT; ++i) out[i] = ctx->dbg[i];
+  return ST_COUNT;
 }
 
 int srz_sync(srz_ctx *ctx) {

@@ -21,6 +21,21 @@ struct __attribute__((aligned(8))) BBox {
   int16_t sx, sy, ex, ey;
 };
 
+// One entry of a band's triangle list: everything the coverage/z pass needs, gathered once by k_bands so that the
+// tile waves read their work with ONE level of (prefetchable, coalesced) loads.
+struct __attribute__((aligned(16))) RasterRec {
+  float ax, ay, z0, bx, by, z1, cx, cy, z2;
+  uint32_t bbx; // sx | sy << 16
+  uint32_t bby; // ex | ey << 16
+  uint32_t idx; // triangle index inside the frame
+};
+
+// What the Shader object bound to a batch holds (type + texture), resolved on the host at render time
+struct __attribute__((aligned(8))) ShadeDescG {
+  int32_t shader, tw, th, _pad;
+  const uint32_t *tex;
+};
+
 struct FrameDesc {
   int32_t width, height;
   float eye[3];
@@ -32,7 +47,7 @@ struct FrameDesc {
   uint32_t n_batches, batch_off; // into batches[]
   uint32_t flags;
   uint32_t n_local_bands;        // bands of this frame owned by this ctx
-  uint64_t list_off;             // into band_lists[] (entries): local band lb at list_off + lb * n_tris
+  uint64_t list_off;             // into band_recs[] (entries): local band lb at list_off + lb * n_tris
   uint32_t count_off;            // into band_count[]: local band lb at count_off + lb
   uint32_t _pad;
 };
@@ -48,7 +63,8 @@ struct TexDesc {
 };
 
 // counters accumulated by the STATS kernel variants (same order as srz_stats)
-enum { ST_TRIS = 0, ST_CULLED, ST_PIXEL_TESTS, ST_FRAGMENTS, ST_SHADED, ST_VISIBLE, ST_VISIBLE_TEX, ST_COUNT };
+enum { ST_TRIS = 0, ST_CULLED, ST_PIXEL_TESTS, ST_FRAGMENTS, ST_SHADED, ST_VISIBLE, ST_VISIBLE_TEX,
+       ST_DBG_CYC_A, ST_DBG_CYC_B, ST_DBG_CYC_C, ST_DBG_MAX_WAVE, ST_DBG_SHADE_CALLS, ST_DBG_BLOCKS, ST_COUNT };
 
 struct RenderArgs {
   const FrameDesc *frames;
@@ -58,8 +74,13 @@ struct RenderArgs {
   const BatchDesc *batches;
   const srz_light *lights;
   const TexDesc *tex;
-  const uint32_t *band_lists;
+  const ShadeDescG *sdesc;       // per batch (indexed like batches[])
+  const RasterRec *band_recs;
   const uint32_t *band_count;
+  uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
+  uint32_t *worklist;            // tiles that need shading: (frame*n_local_bands + lb)*tiles_x + tx
+  uint32_t *work_count;
+  uint32_t tiles_x, n_local_bands;
   float *out;             // [frame][4][local_rows][width]
   uint64_t frame_stride;  // floats per frame in out = 4*local_rows*width
   uint32_t local_rows;    // rows per plane in out
@@ -69,9 +90,10 @@ struct RenderArgs {
 };
 
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
-void launch_bands(const RenderArgs &a, uint32_t *band_lists, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
+void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
                   hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s);
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s);
 void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s);
 
 } // namespace srz

@@ -5,16 +5,20 @@
 // Not a translation of the AVX2 code: the reference walks triangles serially and rows in parallel; here
 //
 //   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox record
-//   k_bands   one WAVE per 32-row band     in-order scan of the BBox stream, ballot-compacted → per-band triangle list
-//                                          (submission order preserved by construction: no atomics, no sort)
-//   k_raster  one WAVE per 32x32 tile      tile z-buffer + owner-id planes in LDS; walks its band's list in order,
-//                                          per triangle the 64 lanes cover 8x8 pixel blocks of bbox∩tile, run the
-//                                          coverage + z-test with the reference's per-column semantics and update LDS
-//                                          (a wave's LDS ops are ordered → "last writer in submission order wins"
-//                                          needs no lock).  Then VISIBILITY-FIRST SHADING: each pixel's final owner is
-//                                          shaded exactly once (the reference's shaders are pure functions of
-//                                          (triangle,pixel), its write is an overwrite) and the four planes leave as
-//                                          16-byte-per-lane non-temporal stores.  Clear is fused (LDS init).
+//   k_bands   one WAVE per 32-row band     in-order scan of the BBox stream, ballot-compacted → per-band list of 48-byte
+//                                          RasterRec (positions + bbox + index), submission order preserved by
+//                                          construction: no atomics, no sort
+//   k_raster  one WAVE per 32x32 tile      VISIBILITY: tile z-buffer + owner-id planes in LDS; walks its band's list in
+//                                          order (next chunk prefetched), per triangle the 64 lanes cover 8x8 pixel blocks
+//                                          of bbox∩tile, run the coverage + z-test with the reference's per-column
+//                                          semantics and update LDS (a wave's LDS ops are ordered → "last writer in
+//                                          submission order wins" needs no lock).  Tiles nobody owns leave as the fused
+//                                          clear (16-byte non-temporal stores of +inf / 0); owned tiles write z + owner ids
+//                                          and enqueue themselves for shading.
+//   k_shade   one WORKGROUP per owned tile VISIBILITY-FIRST SHADING: each pixel's final owner is shaded exactly once (the
+//                                          reference's shaders are pure functions of (triangle,pixel) and its write is an
+//                                          overwrite), all 1024 pixels of the tile in parallel, 16-byte stores of the 3
+//                                          colour planes.
 //
 // Numerics: every float op is the oracle's op in the oracle's order (oracle/srz_oracle.c): contraction is OFF,
 // fused ops are explicit fmaf(), division and sqrt are the correctly rounded ones, pow is evaluated in binary64
@@ -24,6 +28,14 @@
 #pragma clang fp contract(off)
 
 namespace srz {
+
+// Read-only inputs are read through the CONSTANT address space: wave-uniform addresses become scalar (s_load)
+// loads, per-lane ones become invariant loads that never have to be ordered against the framebuffer stores.
+#define SRZ_CAS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const SRZ_CAS T *as_const(const T *p) { return (const SRZ_CAS T *)(p); }
+// native vector types (HIP's float4/uint2 classes cannot be loaded through an address-space-qualified pointer)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- operand-order-exact min/max (SSE / std:: semantics, see oracle) ------------------------------------------
 __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
@@ -114,12 +126,13 @@ __device__ __forceinline__ bool cover_s(const TriXY &t, float fx, float fy, floa
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
-  const FrameDesc &fd = a.frames[blockIdx.y];
-  const int W = fd.width, H = fd.height;
-  const float ex = fd.eye[0], ey = fd.eye[1], ez = fd.eye[2];
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
+  const int W = fd->width, H = fd->height;
+  const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
+  const float ex = fd->eye[0], ey = fd->eye[1], ez = fd->eye[2];
   unsigned long long n_culled = 0, tests = 0;
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < fd.n_tris; t += gridDim.x * 256) {
-    const float *p = &a.tris[fd.tri_off + t].pos[0][0];
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n_tris; t += gridDim.x * 256) {
+    const SRZ_CAS float *p = as_const(&a.tris[tri_off + t].pos[0][0]);
     float A0 = p[0], A1 = p[1], A2 = p[2], B0 = p[3], B1 = p[4], B2 = p[5], C0 = p[6], C1 = p[7], C2 = p[8];
     BBox bb;
     bb.sx = 1, bb.sy = 1, bb.ex = 0, bb.ey = 0;
@@ -152,93 +165,131 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
     } else if (STATS) {
       n_culled++;
     }
-    bbox_out[fd.tri_off + t] = bb;
+    bbox_out[tri_off + t] = bb;
   }
   if (STATS) {
     if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
     if (tests) atomicAdd(&a.stats[ST_PIXEL_TESTS], tests);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[ST_TRIS], (unsigned long long)fd.n_tris);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[ST_TRIS], (unsigned long long)n_tris);
   }
 }
 
 // ================================================================================================================
-// k_bands — one wave per (frame, local band): ordered ballot compaction of the triangles whose bbox touches the band
+// k_bands — one wave per (frame, local band): ordered ballot compaction of the triangles whose bbox touches the band.
+// Hits are queued (indices, LDS) and flushed 64 at a time: the flush gathers positions + bbox with independent loads
+// (one memory round trip per 64 hits) and writes coalesced 48-byte RasterRec entries.
 // ================================================================================================================
-__global__ __launch_bounds__(256) void k_bands(RenderArgs a, uint32_t *band_lists, uint32_t *band_count) {
-  const FrameDesc &fd = a.frames[blockIdx.y];
+__global__ __launch_bounds__(256) void k_bands(RenderArgs a, RasterRec *band_recs, uint32_t *band_count) {
+  __shared__ uint32_t s_q[WAVES_PER_WG][128];
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const uint32_t lb = blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6);
-  if (lb >= fd.n_local_bands) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lb = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
+  if (lb >= fd->n_local_bands) return;
+  const uint32_t n_tris = fd->n_tris;
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
-  uint32_t *list = band_lists + fd.list_off + (uint64_t)lb * fd.n_tris;
-  const BBox *bbox = a.bbox + fd.tri_off;
-  uint32_t cursor = 0;
-  for (uint32_t base = 0; base < fd.n_tris; base += 64) {
-    uint32_t t = base + lane;
-    bool hit = false;
-    if (t < fd.n_tris) {
-      BBox bb = bbox[t];
-      hit = bb.sx <= bb.ex && bb.sy <= y1 && bb.ey >= y0;
+  RasterRec *out = band_recs + fd->list_off + (uint64_t)lb * n_tris;
+  const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
+  const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
+  uint32_t *q = s_q[wave];
+  uint32_t cursor = 0, nq = 0;
+  auto flush = [&](uint32_t n) { // n <= 64 queued indices → records
+    if ((uint32_t)lane < n) {
+      const uint32_t t = q[lane];
+      const u32x2 r = bbox[t];
+      const SRZ_CAS float *p = &tris[t].pos[0][0];
+      RasterRec rec;
+      rec.ax = p[0], rec.ay = p[1], rec.z0 = p[2], rec.bx = p[3], rec.by = p[4], rec.z1 = p[5];
+      rec.cx = p[6], rec.cy = p[7], rec.z2 = p[8];
+      rec.bbx = r.x, rec.bby = r.y, rec.idx = t;
+      out[cursor + lane] = rec;
     }
-    unsigned long long m = __ballot(hit);
-    if (hit) list[cursor + __popcll(m & ((1ull << lane) - 1ull))] = t;
-    cursor += (uint32_t)__popcll(m);
+    cursor += n;
+  };
+  for (uint32_t base = 0; base < n_tris; base += 64) {
+    const uint32_t t = base + lane;
+    bool hit = false;
+    if (t < n_tris) {
+      const u32x2 r = bbox[t];
+      const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
+      hit = sx <= ex && sy <= y1 && ey >= y0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    nq += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (nq >= 64) {
+      flush(64);
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t rest = nq - 64; // < 64
+      uint32_t mv = 0;
+      if ((uint32_t)lane < rest) mv = q[64 + lane];
+      __builtin_amdgcn_wave_barrier();
+      if ((uint32_t)lane < rest) q[lane] = mv;
+      nq = rest;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  if (lane == 0) band_count[fd.count_off + lb] = cursor;
+  if (nq) flush(nq);
+  if (lane == 0) band_count[fd->count_off + lb] = cursor;
 }
 
 // ================================================================================================================
 // Fragment shaders
 // ================================================================================================================
-struct ShadeEnv {
-  const FrameDesc *fd;
-  const srz_light *lights;
-  const TexDesc *tex;
+struct FrameK { // per-frame constants, wave-uniform (live in SGPRs)
+  float eye[3], ka[3], ks[3], p, kh, kn;
+  uint32_t n_lights;
+  const SRZ_CAS srz_light *lights;
+};
+struct ShadeDesc { // what a batch's Shader object holds: type + texture (Shader::texture, width_256/height_256)
+  int shader, tw, th;
+  const SRZ_CAS uint32_t *tex;
 };
 
 // BlinnPhong<__m256> for one light (include/shader/Shader.hpp:104-229)
-__device__ __forceinline__ void v_blinn_phong(float nx, float ny, float nz, const float *ka, float kdr, float kdg, float kdb,
-                                              const float *ks, const float *cam, const srz_light &L, float px, float py,
-                                              float pz, float p, float &o0, float &o1, float &o2) {
-  float lx = L.pos[0] - px, ly = L.pos[1] - py, lz = L.pos[2] - pz;
+__device__ __forceinline__ void v_blinn_phong(float nx, float ny, float nz, const FrameK &K, float kdr, float kdg, float kdb,
+                                              const SRZ_CAS srz_light *L, float px, float py, float pz, float &o0, float &o1,
+                                              float &o2) {
+  const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
+  float lx = Lx - px, ly = Ly - py, lz = Lz - pz;
   float att = 1.0f / __builtin_sqrtf(fmaf_(lx, lx, ly * ly));
-  float d0 = L.intensity[0] * att, d1 = L.intensity[1] * att, d2 = L.intensity[2] * att;
-  float hx = lx + (cam[0] - px), hy = ly + (cam[1] - py), hz = lz + (cam[2] - pz);
+  float d0 = I0 * att, d1 = I1 * att, d2 = I2 * att;
+  float hx = lx + (K.eye[0] - px), hy = ly + (K.eye[1] - py), hz = lz + (K.eye[2] - pz);
   v_normalized(hx, hy, hz);
   float nlx = lx, nly = ly, nlz = lz;
   v_normalized(nlx, nly, nlz);
   float cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
-  float cosT = pow_cr(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), p);
-  o0 = kdr * fmaf_(ka[0], L.intensity[0], fmaf_(d0 * kdr, cosA, (d0 * ks[0]) * cosT));
-  o1 = kdg * fmaf_(ka[1], L.intensity[1], fmaf_(d1 * kdg, cosA, (d1 * ks[1]) * cosT));
-  o2 = kdb * fmaf_(ka[2], L.intensity[2], fmaf_(d2 * kdb, cosA, (d2 * ks[2]) * cosT));
+  float cosT = pow_cr(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+  o0 = kdr * fmaf_(K.ka[0], I0, fmaf_(d0 * kdr, cosA, (d0 * K.ks[0]) * cosT));
+  o1 = kdg * fmaf_(K.ka[1], I1, fmaf_(d1 * kdg, cosA, (d1 * K.ks[1]) * cosT));
+  o2 = kdb * fmaf_(K.ka[2], I2, fmaf_(d2 * kdb, cosA, (d2 * K.ks[2]) * cosT));
 }
 
 // Shader::applyFragmentShader SIMD overload + simd_*_impl (src/Shader.cpp:128-386); colour out in [0,255]
-__device__ __forceinline__ void v_shade(const ShadeEnv &env, int shader, const TexDesc &tx, float px, float py, float pz,
-                                        float nx, float ny, float nz, float u, float v, float &r0, float &r1, float &r2) {
-  const FrameDesc &fd = *env.fd;
+__device__ __forceinline__ void v_shade(const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
+                                        float nz, float u, float v, float &r0, float &r1, float &r2) {
   float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f;
-  if (shader == SRZ_SHADER_NORMAL) {
+  if (sd.shader == SRZ_SHADER_NORMAL) {
     c0 = (nx + 1.0f) * 0.5f, c1 = (ny + 1.0f) * 0.5f, c2 = (nz + 1.0f) * 0.5f;
-  } else if (shader == SRZ_SHADER_TEXTURE || shader == SRZ_SHADER_PHONG) {
+  } else if (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_PHONG) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
-    if (shader == SRZ_SHADER_TEXTURE) {
-      float tw = (float)tx.w, th = (float)tx.h;
+    if (sd.shader == SRZ_SHADER_TEXTURE) {
+      float tw = (float)sd.tw, th = (float)sd.th;
       u = u * tw, v = v * th;
       u = sse_max(0.0f, sse_min(u, tw - 1.0f));
       v = sse_max(0.0f, sse_min(v, th - 1.0f));
       int32_t xi = cvt_rne_i32(u), yi = cvt_rne_i32(v);
-      uint32_t texel = tx.bgrx[(size_t)yi * tx.w + xi];
+      uint32_t texel = sd.tex[(size_t)yi * sd.tw + xi];
       const float inv255 = 1.0f / 255.0f;
       kd0 = (float)(texel & 0xffu) * inv255, kd1 = (float)((texel >> 8) & 0xffu) * inv255,
       kd2 = (float)((texel >> 16) & 0xffu) * inv255;
     }
     c0 = c1 = c2 = 0.0f;
-    for (uint32_t l = 0; l < fd.n_lights; ++l) {
+    for (uint32_t l = 0; l < K.n_lights; ++l) {
       float o0, o1, o2;
-      v_blinn_phong(nx, ny, nz, fd.ka, kd0, kd1, kd2, fd.ks, fd.eye, env.lights[l], px, py, pz, fd.p, o0, o1, o2);
+      v_blinn_phong(nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
   }
@@ -249,52 +300,53 @@ __device__ __forceinline__ void v_shade(const ShadeEnv &env, int shader, const T
 }
 
 // TextureLoader::getTextureColor(vec2) (src/TextureLoader.cpp:14-31)
-__device__ __forceinline__ void s_texel(const TexDesc &tx, float u, float v, float &o0, float &o1, float &o2) {
+__device__ __forceinline__ void s_texel(const ShadeDesc &sd, float u, float v, float &o0, float &o1, float &o2) {
   float cu = std_clamp(u, 0.0f, 1.0f), cv = std_clamp(v, 0.0f, 1.0f);
-  float fx = cu * (float)tx.w, fy = cv * (float)tx.h;
+  float fx = cu * (float)sd.tw, fy = cv * (float)sd.th;
   int x = (int)fx, y = (int)fy;
-  if (x < 0 || x >= tx.w || y < 0 || y >= tx.h) {
+  if (x < 0 || x >= sd.tw || y < 0 || y >= sd.th) {
     o0 = o1 = o2 = 0.0f;
     return;
   }
-  uint32_t texel = tx.bgrx[(size_t)y * tx.w + x];
+  uint32_t texel = sd.tex[(size_t)y * sd.tw + x];
   o0 = (float)(texel & 0xffu) / 255.0f, o1 = (float)((texel >> 8) & 0xffu) / 255.0f,
   o2 = (float)((texel >> 16) & 0xffu) / 255.0f;
 }
 
 // Shader::BlinnPhong scalar (src/Shader.cpp:510-543); the two std::pow(x,2) and the sqrt are binary64 there
-__device__ __forceinline__ void s_blinn_phong(const float *cam, float px, float py, float pz, float nx, float ny, float nz,
-                                              float kd0, float kd1, float kd2, const srz_light &L, const float *ka,
-                                              const float *ks, float p, float &o0, float &o1, float &o2) {
+__device__ __forceinline__ void s_blinn_phong(const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
+                                              float kd0, float kd1, float kd2, const SRZ_CAS srz_light *L, float &o0, float &o1,
+                                              float &o2) {
+  const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
   normalize3(nx, ny, nz);
-  float ldx = L.pos[0] - px, ldy = L.pos[1] - py, ldz = L.pos[2] - pz;
-  double dx = (double)(L.pos[0] - px), dy = (double)(L.pos[1] - py);
+  float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
+  double dx = (double)(Lx - px), dy = (double)(Ly - py);
   float dsq = (float)__builtin_sqrt(dx * dx + dy * dy);
-  float d0 = L.intensity[0] / dsq, d1 = L.intensity[1] / dsq, d2 = L.intensity[2] / dsq;
+  float d0 = I0 / dsq, d1 = I1 / dsq, d2 = I2 / dsq;
   float nlx = ldx, nly = ldy, nlz = ldz;
   normalize3(nlx, nly, nlz);
   float cosTheta = std_max(0.0f, dot3(nx, ny, nz, nlx, nly, nlz));
-  float vx = cam[0] - px, vy = cam[1] - py, vz = cam[2] - pz;
+  float vx = K.eye[0] - px, vy = K.eye[1] - py, vz = K.eye[2] - pz;
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
   normalize3(hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
-  float pw = pow_cr(cosAlpha, p);
-  o0 = ((ka[0] * L.intensity[0] + (cosTheta * kd0) * d0) + (pw * ks[0]) * d0) * kd0;
-  o1 = ((ka[1] * L.intensity[1] + (cosTheta * kd1) * d1) + (pw * ks[1]) * d1) * kd1;
-  o2 = ((ka[2] * L.intensity[2] + (cosTheta * kd2) * d2) + (pw * ks[2]) * d2) * kd2;
+  float pw = pow_cr(cosAlpha, K.p);
+  o0 = ((K.ka[0] * I0 + (cosTheta * kd0) * d0) + (pw * K.ks[0]) * d0) * kd0;
+  o1 = ((K.ka[1] * I1 + (cosTheta * kd1) * d1) + (pw * K.ks[1]) * d1) * kd1;
+  o2 = ((K.ka[2] * I2 + (cosTheta * kd2) * d2) + (pw * K.ks[2]) * d2) * kd2;
 }
 
 // calcBumpMapping / calcDisplacementMapping common part (src/Shader.cpp:447-507)
-__device__ __forceinline__ void s_bump_common(const TexDesc &tx, float nx, float ny, float nz, float u, float v, float kh,
+__device__ __forceinline__ void s_bump_common(const ShadeDesc &sd, float nx, float ny, float nz, float u, float v, float kh,
                                               float kn, float &ox, float &oy, float &oz, float &origin_norm) {
   float sq = __builtin_sqrtf(nx * nx + nz * nz);
   float t0 = (nx * ny) / sq, t1 = sq, t2 = (nz * ny) / sq;
   float b0 = ny * t2 - t1 * nz, b1 = nz * t0 - t2 * nx, b2 = nx * t1 - t0 * ny;
   float a0, a1, a2, u0, u1, u2, w0, w1, w2;
-  s_texel(tx, u, v, a0, a1, a2);
+  s_texel(sd, u, v, a0, a1, a2);
   float on = __builtin_sqrtf(dot3(a0, a1, a2, a0, a1, a2));
-  s_texel(tx, (u + 1.0f) / (float)tx.w, v, u0, u1, u2);
-  s_texel(tx, u, (v + 1.0f) / (float)tx.h, w0, w1, w2);
+  s_texel(sd, (u + 1.0f) / (float)sd.tw, v, u0, u1, u2);
+  s_texel(sd, u, (v + 1.0f) / (float)sd.th, w0, w1, w2);
   float dU = kh * kn * (__builtin_sqrtf(dot3(u0, u1, u2, u0, u1, u2)) - on);
   float dV = kh * kn * (__builtin_sqrtf(dot3(w0, w1, w2, w0, w1, w2)) - on);
   float l0 = -dU, l1 = -dV, l2 = 1.0f;
@@ -304,28 +356,27 @@ __device__ __forceinline__ void s_bump_common(const TexDesc &tx, float nx, float
 }
 
 // scalar applyFragmentShader + standard_*_impl + Tools::normalizedToRGB (src/Shader.cpp:547-640, src/Tools.cpp:94-104)
-__device__ __forceinline__ void s_shade(const ShadeEnv &env, int shader, const TexDesc &tx, float px, float py, float pz,
-                                        float nx, float ny, float nz, float u, float v, float &r0, float &r1, float &r2) {
-  const FrameDesc &fd = *env.fd;
+__device__ __forceinline__ void s_shade(const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
+                                        float nz, float u, float v, float &r0, float &r1, float &r2) {
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-  if (shader == SRZ_SHADER_NORMAL) {
+  if (sd.shader == SRZ_SHADER_NORMAL) {
     normalize3(nx, ny, nz);
     c0 = (nx + 1.0f) / 2.0f, c1 = (ny + 1.0f) / 2.0f, c2 = (nz + 1.0f) / 2.0f;
-  } else if (shader >= SRZ_SHADER_TEXTURE && shader <= SRZ_SHADER_BUMP) {
+  } else if (sd.shader >= SRZ_SHADER_TEXTURE && sd.shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
     float sx = px, sy = py, sz = pz, snx = nx, sny = ny, snz = nz;
-    if (shader != SRZ_SHADER_PHONG) s_texel(tx, u, v, kd0, kd1, kd2);
-    if (shader == SRZ_SHADER_BUMP) {
+    if (sd.shader != SRZ_SHADER_PHONG) s_texel(sd, u, v, kd0, kd1, kd2);
+    if (sd.shader == SRZ_SHADER_BUMP) {
       float on;
-      s_bump_common(tx, nx, ny, nz, u, v, fd.kh, fd.kn, snx, sny, snz, on);
-    } else if (shader == SRZ_SHADER_DISPLACEMENT) {
+      s_bump_common(sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
+    } else if (sd.shader == SRZ_SHADER_DISPLACEMENT) {
       float on;
-      s_bump_common(tx, nx, ny, nz, u, v, fd.kh, fd.kn, snx, sny, snz, on);
-      sx = px + (fd.kn * nx) * on, sy = py + (fd.kn * ny) * on, sz = pz + (fd.kn * nz) * on;
+      s_bump_common(sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
+      sx = px + (K.kn * nx) * on, sy = py + (K.kn * ny) * on, sz = pz + (K.kn * nz) * on;
     }
-    for (uint32_t l = 0; l < fd.n_lights; ++l) {
+    for (uint32_t l = 0; l < K.n_lights; ++l) {
       float o0, o1, o2;
-      s_blinn_phong(fd.eye, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, env.lights[l], fd.ka, fd.ks, fd.p, o0, o1, o2);
+      s_blinn_phong(K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
   }
@@ -336,25 +387,33 @@ __device__ __forceinline__ void s_shade(const ShadeEnv &env, int shader, const T
   r2 = (q2 == q2) ? (float)(uint32_t)q2 : 0.0f;
 }
 
-// Shade the final owner `idx` of pixel (x,y) with depth z.
-__device__ __forceinline__ void shade_pixel(const RenderArgs &a, const ShadeEnv &env, uint32_t flags, uint32_t idx, int x,
-                                            int y, float z, float &r0, float &r1, float &r2, bool &textured) {
-  const FrameDesc &fd = *env.fd;
-  const float4 *tp = reinterpret_cast<const float4 *>(a.tris + fd.tri_off + idx);
-  float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5];
+// Everything the shader needs about the owner triangle of one pixel, fetched in ONE round trip (7 independent loads)
+struct TriFetch {
+  f32x4 q0, q1, q2, q3, q4, q5;
+  u32x2 bb;
+  uint32_t batch;
+};
+__device__ __forceinline__ void fetch_tri(const SRZ_CAS srz_tri *tris, const SRZ_CAS u32x2 *bbox,
+                                          const SRZ_CAS uint16_t *tri_batch, uint32_t idx, TriFetch &f) {
+  const SRZ_CAS f32x4 *tp = reinterpret_cast<const SRZ_CAS f32x4 *>(tris + idx);
+  f.q0 = tp[0], f.q1 = tp[1], f.q2 = tp[2], f.q3 = tp[3], f.q4 = tp[4], f.q5 = tp[5];
+  f.bb = bbox[idx];
+  f.batch = tri_batch[idx];
+}
+
+// Shade pixel (x,y) of depth z with its final owner `f`.
+__device__ __forceinline__ void shade_pixel(const FrameK &K, const ShadeDesc &sd, uint32_t flags, const TriFetch &f, int x,
+                                            int y, float z, float &r0, float &r1, float &r2) {
   // pos: q0.xyz q0.w q1.xy q1.zw q2.x | nrm: q2.yzw q3.xyz q3.w q4.xy | uv: q4.zw q5.xy q5.zw
   TriXY t;
-  t.ax = q0.x, t.ay = q0.y, t.z0 = q0.z, t.bx = q0.w, t.by = q1.x, t.z1 = q1.y, t.cx = q1.z, t.cy = q1.w, t.z2 = q2.x;
+  t.ax = f.q0.x, t.ay = f.q0.y, t.z0 = f.q0.z, t.bx = f.q0.w, t.by = f.q1.x, t.z1 = f.q1.y, t.cx = f.q1.z, t.cy = f.q1.w,
+  t.z2 = f.q2.x;
   tri_consts(t);
-  const float n0x = q2.y, n0y = q2.z, n0z = q2.w, n1x = q3.x, n1y = q3.y, n1z = q3.z, n2x = q3.w, n2y = q4.x, n2z = q4.y;
-  const float u0 = q4.z, v0 = q4.w, u1 = q5.x, v1 = q5.y, u2 = q5.z, v2 = q5.w;
-  const BBox bb = a.bbox[fd.tri_off + idx];
-  const int vend = (flags & SRZ_UNIFIED) ? bb.ex + 1 : bb.sx + ((bb.ex - bb.sx + 1) & ~7);
-  const BatchDesc bd = a.batches[fd.batch_off + a.tri_batch[fd.tri_off + idx]];
-  TexDesc tx;
-  tx.bgrx = nullptr, tx.w = 1, tx.h = 1;
-  textured = bd.shader == SRZ_SHADER_TEXTURE || bd.shader == SRZ_SHADER_DISPLACEMENT || bd.shader == SRZ_SHADER_BUMP;
-  if (textured) tx = env.tex[bd.tex_id];
+  const float n0x = f.q2.y, n0y = f.q2.z, n0z = f.q2.w, n1x = f.q3.x, n1y = f.q3.y, n1z = f.q3.z, n2x = f.q3.w, n2y = f.q4.x,
+              n2z = f.q4.y;
+  const float u0 = f.q4.z, v0 = f.q4.w, u1 = f.q5.x, v1 = f.q5.y, u2 = f.q5.z, v2 = f.q5.w;
+  const int sx = (int16_t)(f.bb.x & 0xffff), ex = (int16_t)(f.bb.y & 0xffff);
+  const int vend = (flags & SRZ_UNIFIED) ? ex + 1 : sx + ((ex - sx + 1) & ~7);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
   if (x < vend) {
@@ -365,7 +424,7 @@ __device__ __forceinline__ void shade_pixel(const RenderArgs &a, const ShadeEnv 
     v_normalized(nx, ny, nz);
     float u = fmaf_(alpha, u0, fmaf_(beta, u1, gamma * u2));
     float v = fmaf_(alpha, v0, fmaf_(beta, v1, gamma * v2));
-    v_shade(env, bd.shader, tx, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+    v_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
   } else {
     cover_s(t, fx, fy, alpha, beta, gamma, zz);
     float nx = alpha * n0x + beta * n1x + gamma * n2x;
@@ -374,19 +433,19 @@ __device__ __forceinline__ void shade_pixel(const RenderArgs &a, const ShadeEnv 
     normalize3(nx, ny, nz);
     float u = alpha * u0 + beta * u1 + gamma * u2;
     float v = alpha * v0 + beta * v1 + gamma * v2;
-    s_shade(env, bd.shader, tx, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+    s_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
   }
 }
 
 // ================================================================================================================
-// k_raster — one wave per 32x32 tile
+// k_raster — VISIBILITY: one wave per 32x32 tile
 // ================================================================================================================
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// streaming 16-byte store: the framebuffer is written once and never re-read by this kernel
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+// streaming 16-byte store: written once, never re-read by this pipeline
 __device__ __forceinline__ void store_nt(float *p, const float4 &v) {
   f32x4 w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, reinterpret_cast<f32x4 *>(p));
@@ -397,24 +456,29 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_z[WAVES_PER_WG][TILE * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) uint32_t s_id[WAVES_PER_WG][TILE * LDS_STRIDE];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const FrameDesc &fd = a.frames[blockIdx.z];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: everything derived stays in SGPRs
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.z;
   const uint32_t lb = blockIdx.y;
-  if (lb >= fd.n_local_bands) return;
-  const int W = fd.width, H = fd.height;
+  if (lb >= fd->n_local_bands) return;
+  const int W = fd->width, H = fd->height;
+  const uint32_t n_tris = fd->n_tris;
+  const uint32_t flags = fd->flags | a.flags_or;
   const int tx0 = ((int)blockIdx.x * WAVES_PER_WG + wave) * TILE;
-  if (tx0 >= W) return; // the whole wave leaves; no workgroup barrier is used anywhere in this kernel
+  if (tx0 >= W) return; // whole wave leaves; no workgroup barrier is used in this kernel
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int ty0 = band * BAND;
   const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
-  const uint32_t flags = fd.flags | a.flags_or;
   const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
   float *zl = s_z[wave];
   uint32_t *il = s_id[wave];
 
   const size_t plane = (size_t)a.local_rows * (size_t)W;
-  float *out0 = a.out + (size_t)blockIdx.z * a.frame_stride + ((size_t)lb * BAND) * (size_t)W; // plane 0 (z), row ty0
+  const size_t row0 = (size_t)lb * BAND;
+  float *out0 = a.out + (size_t)blockIdx.z * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
+  uint32_t *vis0 = a.vis + ((size_t)blockIdx.z * a.local_rows + row0) * (size_t)W;
 
+  const unsigned long long tA = STATS ? __builtin_readcyclecounter() : 0;
   // ---- phase A: tile init (fused clear → +inf, else load the in/out z plane) ---------------------------------
   for (int i = lane; i < TILE * TILE; i += 64) {
     int ly = i >> 5, lx = i & 31;
@@ -425,44 +489,52 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
   }
   __builtin_amdgcn_wave_barrier();
 
+  const unsigned long long tB = STATS ? __builtin_readcyclecounter() : 0;
+  unsigned long long n_blocks = 0;
   // ---- phase B: walk the band's triangle list in submission order ---------------------------------------------
-  const uint32_t cnt = a.band_count[fd.count_off + lb];
-  const uint32_t *list = a.band_lists + fd.list_off + (uint64_t)lb * fd.n_tris;
-  const BBox *bbox = a.bbox + fd.tri_off;
-  const srz_tri *tris = a.tris + fd.tri_off;
+  const uint32_t cnt = (flags & 0x100u) ? 0u : a.band_count[fd->count_off + lb];
+  const SRZ_CAS f32x4 *recs =
+      reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.band_recs) + fd->list_off + (uint64_t)lb * n_tris);
   unsigned long long n_frag = 0, n_shaded = 0;
+  bool any_owner = false;
 
+  // software pipeline: the next chunk's records are in flight while the current chunk is rasterised
+  f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0, n2 = n0;
+  bool nv = false;
+  if ((uint32_t)lane < cnt) {
+    n0 = recs[3 * lane], n1 = recs[3 * lane + 1], n2 = recs[3 * lane + 2];
+    nv = true;
+  }
   for (uint32_t base = 0; base < cnt; base += 64) {
-    uint32_t my = NO_TRI;
-    BBox bb;
-    bb.sx = 1, bb.ex = 0, bb.sy = 0, bb.ey = 0;
+    const f32x4 r0 = n0, r1 = n1, r2 = n2;
+    const bool valid = nv;
+    nv = false;
+    if (base + 64 + lane < cnt) {
+      const uint32_t e = base + 64 + lane;
+      n0 = recs[3 * e], n1 = recs[3 * e + 1], n2 = recs[3 * e + 2];
+      nv = true;
+    }
+    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx
+    // (by-value helper: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
+    const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z), my = f2u(r2.w);
+    const int bsx = (int16_t)(bbx & 0xffff), bex = (int16_t)(bby & 0xffff);
+    const bool hit = valid && bex >= tx0 && bsx <= tx1;
     TriXY t;
-    t.ax = t.ay = t.bx = t.by = t.cx = t.cy = t.z0 = t.z1 = t.z2 = t.v_inv = t.s_area = 0.0f;
-    bool hit = false;
-    if (base + lane < cnt) {
-      my = list[base + lane];
-      bb = bbox[my];
-      hit = bb.ex >= tx0 && bb.sx <= tx1;
-    }
-    if (hit) {
-      const float *p = &tris[my].pos[0][0];
-      t.ax = p[0], t.ay = p[1], t.z0 = p[2], t.bx = p[3], t.by = p[4], t.z1 = p[5], t.cx = p[6], t.cy = p[7], t.z2 = p[8];
-      tri_consts(t);
-    }
-    const int bbx = (int)(uint16_t)bb.sx | ((int)(uint16_t)bb.ex << 16);
-    const int bby = (int)(uint16_t)bb.sy | ((int)(uint16_t)bb.ey << 16);
+    t.ax = r0.x, t.ay = r0.y, t.z0 = r0.z, t.bx = r0.w, t.by = r1.x, t.z1 = r1.y, t.cx = r1.z, t.cy = r1.w, t.z2 = r2.x;
+    t.v_inv = t.s_area = 0.0f;
+    if (hit) tri_consts(t);
     unsigned long long m = __ballot(hit);
     while (m) {
       const int j = __builtin_ctzll(m);
       m &= m - 1;
-      // broadcast triangle j to the wave (uniform values)
+      // broadcast triangle j to the wave (uniform values → SGPRs)
       TriXY u;
       u.ax = rl_f(t.ax, j), u.ay = rl_f(t.ay, j), u.bx = rl_f(t.bx, j), u.by = rl_f(t.by, j), u.cx = rl_f(t.cx, j);
       u.cy = rl_f(t.cy, j), u.z0 = rl_f(t.z0, j), u.z1 = rl_f(t.z1, j), u.z2 = rl_f(t.z2, j);
       u.v_inv = rl_f(t.v_inv, j), u.s_area = rl_f(t.s_area, j);
       const uint32_t idx = (uint32_t)rl_i((int)my, j);
-      const int px = rl_i(bbx, j), py = rl_i(bby, j);
-      const int sx = (int16_t)(px & 0xffff), ex = (int16_t)(px >> 16), sy = (int16_t)(py & 0xffff), ey = (int16_t)(py >> 16);
+      const int px = rl_i((int)bbx, j), py = rl_i((int)bby, j);
+      const int sx = (int16_t)(px & 0xffff), sy = (int16_t)(px >> 16), ex = (int16_t)(py & 0xffff), ey = (int16_t)(py >> 16);
       const int rx0 = max(sx, tx0), rx1 = min(ex, tx1), ry0 = max(sy, ty0), ry1 = min(ey, ty1);
       const int vend = (flags & SRZ_UNIFIED) ? ex + 1 : sx + ((ex - sx + 1) & ~7);
       for (int yb = ry0; yb <= ry1; yb += 8) {
@@ -490,78 +562,188 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
             zl[li] = z;
             il[li] = idx;
           }
-          if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0;
+          any_owner |= pass;
+          if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
         }
       }
     }
   }
   __builtin_amdgcn_wave_barrier();
+  const bool tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
 
-  // ---- phase C: shade every pixel's final owner once, write z + 3 colour planes ---------------------------------
-  ShadeEnv env;
-  env.fd = &fd, env.lights = a.lights + fd.light_off, env.tex = a.tex;
-  unsigned long long n_vis = 0, n_vis_tex = 0;
+  const unsigned long long tC = STATS ? __builtin_readcyclecounter() : 0;
+  // ---- phase C: write-out ---------------------------------------------------------------------------------------
+  //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
+  //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
   const bool vec_ok = (W & 3) == 0;
-  for (int it = 0; it < 4; ++it) {
-    const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+  if (tile_has_owner || fused) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it = 0; it < 4; ++it) {
+      const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+      const int y = ty0 + ly, x4 = tx0 + lx4;
+      if (y > ty1 || x4 > tx1) continue;
+      const float4 z4 = *reinterpret_cast<const float4 *>(&zl[ly * LDS_STRIDE + lx4]);
+      float *gz = out0 + (size_t)ly * W + x4;
+      const bool full = vec_ok && x4 + 3 <= tx1;
+      if (tile_has_owner) {
+        const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
+        uint32_t *gv = vis0 + (size_t)ly * W + x4;
+        if (full) {
+          *reinterpret_cast<float4 *>(gz) = z4; // re-read by k_shade: keep it cacheable
+          *reinterpret_cast<uint4 *>(gv) = id4;
+        } else {
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[K_] = z4.M, gv[K_] = id4.M;
+          SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+#undef SRZ_ST
+        }
+      } else {
+        if (full) {
+          store_nt(gz, z4);
+          store_nt(gz + plane, zero4);
+          store_nt(gz + 2 * plane, zero4);
+          store_nt(gz + 3 * plane, zero4);
+        } else {
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[K_] = z4.M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
+          SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+#undef SRZ_ST
+        }
+      }
+    }
+  }
+  if (tile_has_owner && lane == 0) {
+    const uint32_t slot = atomicAdd(a.work_count, 1u);
+    a.worklist[slot] = ((uint32_t)blockIdx.z * a.n_local_bands + lb) * a.tiles_x + (uint32_t)(tx0 / TILE);
+  }
+  if (STATS) {
+    const unsigned long long tD = __builtin_readcyclecounter();
+    for (int o = 32; o > 0; o >>= 1) {
+      n_frag += __shfl_down(n_frag, o);
+      n_shaded += __shfl_down(n_shaded, o);
+      n_blocks += __shfl_down(n_blocks, o);
+    }
+    if (lane == 0) {
+      if (n_frag) atomicAdd(&a.stats[ST_FRAGMENTS], n_frag);
+      if (n_shaded) atomicAdd(&a.stats[ST_SHADED], n_shaded);
+      atomicAdd(&a.stats[ST_DBG_CYC_A], tB - tA);
+      atomicAdd(&a.stats[ST_DBG_CYC_B], tC - tB);
+      atomicAdd(&a.stats[ST_DBG_CYC_C], tD - tC);
+      atomicMax(&a.stats[ST_DBG_MAX_WAVE], tD - tA);
+      atomicAdd(&a.stats[ST_DBG_BLOCKS], n_blocks);
+    }
+  }
+}
+
+// ================================================================================================================
+// k_shade — VISIBILITY-FIRST SHADING: one workgroup per owned tile (persistent grid over the worklist)
+// ================================================================================================================
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n_work = *as_const(a.work_count);
+  unsigned long long n_vis = 0, n_vis_tex = 0, n_calls = 0;
+  for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const uint32_t e = as_const(a.worklist)[w];
+    const uint32_t tx = e % a.tiles_x, rest = e / a.tiles_x;
+    const uint32_t lb = rest % a.n_local_bands, f = rest / a.n_local_bands;
+    const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
+    const int W = fd->width, H = fd->height;
+    const uint32_t tri_off = fd->tri_off, batch_off = fd->batch_off;
+    const uint32_t flags = fd->flags | a.flags_or;
+    const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
+    FrameK K;
+    K.eye[0] = fd->eye[0], K.eye[1] = fd->eye[1], K.eye[2] = fd->eye[2];
+    K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
+    K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
+    K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
+    K.lights = as_const(a.lights) + fd->light_off;
+    const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox)) + tri_off;
+    const SRZ_CAS srz_tri *tris = as_const(a.tris) + tri_off;
+    const SRZ_CAS uint16_t *tri_batch = as_const(a.tri_batch) + tri_off;
+    const SRZ_CAS ShadeDescG *sdesc = as_const(a.sdesc) + batch_off;
+
+    const int band = (int)lb * a.shard_world + a.shard_rank;
+    const int tx0 = (int)tx * TILE, ty0 = band * BAND;
+    const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
+    const size_t plane = (size_t)a.local_rows * (size_t)W;
+    const size_t row0 = (size_t)lb * BAND;
+    float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
+    const uint32_t *vis0 = a.vis + ((size_t)f * a.local_rows + row0) * (size_t)W;
+
+    const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int y = ty0 + ly, x4 = tx0 + lx4;
     if (y > ty1 || x4 > tx1) continue;
-    const float4 z4 = *reinterpret_cast<const float4 *>(&zl[ly * LDS_STRIDE + lx4]);
-    const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
+    const bool full = ((W & 3) == 0) && x4 + 3 <= tx1;
     float *gz = out0 + (size_t)ly * W + x4;
-    float4 C0 = make_float4(0.f, 0.f, 0.f, 0.f), C1 = C0, C2 = C0;
-    const bool full = vec_ok && x4 + 3 <= tx1;
-    if (!fused) { // keep the colour of pixels this call does not own
-      if (full) {
+    const uint32_t *gv = vis0 + (size_t)ly * W + x4;
+    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), C0 = z4, C1 = z4, C2 = z4;
+    uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
+    if (full) {
+      z4 = *reinterpret_cast<const float4 *>(gz);
+      id4 = *reinterpret_cast<const uint4 *>(gv);
+      if (!fused) { // keep the colour of pixels this call does not own
         C0 = *reinterpret_cast<const float4 *>(gz + plane);
         C1 = *reinterpret_cast<const float4 *>(gz + 2 * plane);
         C2 = *reinterpret_cast<const float4 *>(gz + 3 * plane);
-      } else {
-#define SRZ_LD(K, M)                                                                                                   \
-  if (x4 + K <= tx1) C0.M = gz[plane + K], C1.M = gz[2 * plane + K], C2.M = gz[3 * plane + K];
-        SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
-#undef SRZ_LD
       }
+    } else {
+#define SRZ_LD(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) {                                                                                                \
+    z4.M = gz[K_], id4.M = gv[K_];                                                                                     \
+    if (!fused) C0.M = gz[plane + K_], C1.M = gz[2 * plane + K_], C2.M = gz[3 * plane + K_];                           \
+  }
+      SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
+#undef SRZ_LD
     }
+    if (!(flags & 0x200u)) {
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t id = k == 0 ? id4.x : k == 1 ? id4.y : k == 2 ? id4.z : id4.w;
-      const float z = k == 0 ? z4.x : k == 1 ? z4.y : k == 2 ? z4.z : z4.w;
-      if (id != NO_TRI) {
-        float r0, r1, r2;
-        bool textured;
-        shade_pixel(a, env, flags, id, x4 + k, y, z, r0, r1, r2, textured);
-        if (k == 0) C0.x = r0, C1.x = r1, C2.x = r2;
-        if (k == 1) C0.y = r0, C1.y = r1, C2.y = r2;
-        if (k == 2) C0.z = r0, C1.z = r1, C2.z = r2;
-        if (k == 3) C0.w = r0, C1.w = r1, C2.w = r2;
-        if (STATS) n_vis++, n_vis_tex += textured ? 1 : 0;
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t id = k == 0 ? id4.x : k == 1 ? id4.y : k == 2 ? id4.z : id4.w;
+        const float z = k == 0 ? z4.x : k == 1 ? z4.y : k == 2 ? z4.z : z4.w;
+        if (id != NO_TRI) {
+          TriFetch tf;
+          fetch_tri(tris, bbox, tri_batch, id, tf);
+          const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+          ShadeDesc sd;
+          sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+          float r0, r1, r2;
+          shade_pixel(K, sd, flags, tf, x4 + k, y, z, r0, r1, r2);
+          if (k == 0) C0.x = r0, C1.x = r1, C2.x = r2;
+          if (k == 1) C0.y = r0, C1.y = r1, C2.y = r2;
+          if (k == 2) C0.z = r0, C1.z = r1, C2.z = r2;
+          if (k == 3) C0.w = r0, C1.w = r1, C2.w = r2;
+          if (STATS) {
+            const bool textured =
+                sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP;
+            n_vis++, n_vis_tex += textured ? 1 : 0;
+          }
+        }
+        if (STATS && __ballot(id != NO_TRI) != 0 && lane == __builtin_ctzll(__ballot(1))) n_calls++;
       }
     }
     if (full) {
-      store_nt(gz, z4);
       store_nt(gz + plane, C0);
       store_nt(gz + 2 * plane, C1);
       store_nt(gz + 3 * plane, C2);
     } else {
-#define SRZ_ST(K, M)                                                                                                   \
-  if (x4 + K <= tx1) gz[K] = z4.M, gz[plane + K] = C0.M, gz[2 * plane + K] = C1.M, gz[3 * plane + K] = C2.M;
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[plane + K_] = C0.M, gz[2 * plane + K_] = C1.M, gz[3 * plane + K_] = C2.M;
       SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
     }
   }
   if (STATS) {
     for (int o = 32; o > 0; o >>= 1) {
-      n_frag += __shfl_down(n_frag, o);
-      n_shaded += __shfl_down(n_shaded, o);
       n_vis += __shfl_down(n_vis, o);
       n_vis_tex += __shfl_down(n_vis_tex, o);
+      n_calls += __shfl_down(n_calls, o);
     }
     if (lane == 0) {
-      if (n_frag) atomicAdd(&a.stats[ST_FRAGMENTS], n_frag);
-      if (n_shaded) atomicAdd(&a.stats[ST_SHADED], n_shaded);
       if (n_vis) atomicAdd(&a.stats[ST_VISIBLE], n_vis);
       if (n_vis_tex) atomicAdd(&a.stats[ST_VISIBLE_TEX], n_vis_tex);
+      if (n_calls) atomicAdd(&a.stats[ST_DBG_SHADE_CALLS], n_calls);
     }
   }
 }
@@ -587,11 +769,20 @@ void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool sta
     hipLaunchKernelGGL(k_setup<false>, grid, dim3(256), 0, s, a, bb);
 }
 
-void launch_bands(const RenderArgs &a, uint32_t *band_lists, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
+void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
                   hipStream_t s) {
   if (n_frames <= 0 || max_local_bands == 0) return;
   dim3 grid((max_local_bands + WAVES_PER_WG - 1) / WAVES_PER_WG, n_frames);
-  hipLaunchKernelGGL(k_bands, grid, dim3(256), 0, s, a, band_lists, band_count);
+  hipLaunchKernelGGL(k_bands, grid, dim3(256), 0, s, a, band_recs, band_count);
+}
+
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s) {
+  if (max_tiles == 0) return;
+  dim3 grid(max_tiles < 4096u ? max_tiles : 4096u); // persistent: workgroups stride over the worklist
+  if (stats)
+    hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), 0, s, a);
 }
 
 void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s) {

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync"]
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters"]
 
 
 class SrzError(RuntimeError):
@@ -53,9 +53,10 @@ def lib():
         L.srz_frameset_stats.argtypes = [vp, vp, C.POINTER(abi.SrzStats)]
         L.srz_frameset_algorithmic_bytes.argtypes = [vp, vp]
         L.srz_frameset_algorithmic_bytes.restype = C.c_uint64
-        L.srz_kernel_time_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.srz_kernel_time_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.srz_set_kernel_timing.argtypes = [vp, C.c_int]
         L.srz_sync.argtypes = [vp]
+        L.srz_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         _lib = L
     return _lib
 
@@ -149,9 +150,14 @@ class Context:
         self._check(lib().srz_set_kernel_timing(self.h, 1 if on else 0))
 
     def kernel_time_ms(self, reset=True):
-        r, t, n = C.c_double(), C.c_double(), C.c_int()
-        self._check(lib().srz_kernel_time_ms(self.h, 1 if reset else 0, C.byref(r), C.byref(t), C.byref(n)))
-        return r.value, t.value, n.value
+        ms, n = (C.c_double * 4)(), C.c_int()
+        self._check(lib().srz_kernel_time_ms(self.h, 1 if reset else 0, ms, C.byref(n)))
+        return {"bin_ms": ms[0], "raster_ms": ms[1], "shade_ms": ms[2], "total_ms": ms[3], "launches": n.value}
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 32)()
+        n = lib().srz_debug_counters(self.h, out, 32)
+        return [int(out[i]) for i in range(n)]
 
     def sync(self):
         self._check(lib().srz_sync(self.h))

@@ -1,0 +1,50 @@
+"""Dev tool (not a test, not the bench): time the frameset path on the GPU for a config.
+usage: python tests/perf_probe.py [config=2] [frames=64] [iters=20]"""
+import sys
+import time
+
+import conftest  # noqa: F401  (sys.path)
+import numpy as np
+import torch
+
+import scenes
+import srz
+from srz import abi
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+dbg = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
+builder = {2: scenes.config2, 3: scenes.config3, 4: scenes.config4, 5: scenes.config5}[cfg]
+t0 = time.time()
+import os
+kw = {}
+if os.environ.get('PROBE_SHADER') is not None and cfg == 2:
+    kw['shader'] = int(os.environ['PROBE_SHADER'])
+uniq = [builder(i, **kw) for i in range(min(F, 36))]
+frames = [uniq[i % len(uniq)] for i in range(F)]
+print(f"built {len(uniq)} frames in {time.time()-t0:.1f}s; tris/frame={frames[0].n_tris}")
+ctx = srz.Context(0)
+ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+fs = ctx.frameset(frames)
+st = fs.stats()
+print("stats", st)
+dbg_c = ctx.debug_counters()
+print("dbg cycles A,B,C,maxwave,shade_calls,blocks:", dbg_c[7:13])
+out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+ctx.set_kernel_timing(True)
+for _ in range(3):
+    fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | dbg, stream)
+torch.cuda.synchronize()
+ctx.kernel_time_ms(True)
+t0 = time.time()
+for _ in range(iters):
+    fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | dbg, stream)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / iters
+kt = ctx.kernel_time_ms(True)
+ab = fs.algorithmic_bytes()
+print(f"F={F} wall/render={dt*1e3:.3f} ms  " + " ".join(f"{k}={v:.3f}" if k != "launches" else f"{k}={v}" for k, v in kt.items()))
+print(f"frames/s={F/dt:.0f}  Mfrag/s={st['fragments']/dt/1e6:.1f}  algorithmic bytes={ab/1e6:.1f} MB  "
+      f"achieved={ab/(kt['total_ms']*1e-3)/1e9:.1f} GB/s (pipeline, events)  {ab/dt/1e9:.1f} GB/s (wall)")
