@@ -1,0 +1,557 @@
+// SoftRasterizer.cpp — host layer above the C ABI (see include/SoftRasterizer.hpp).
+// Citations are into Liupeter01/Software-Rasterizer.
+#include "SoftRasterizer.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../../include/srz.h"
+
+namespace SoftRasterizer {
+
+namespace detail {
+void load_image_bgr(const std::string &path, std::vector<uint8_t> &bgr, int &W, int &H);
+
+// stand-in for spdlog::error / warn (spdlog is an absent submodule of the reference)
+static void log(const char *level, const char *fmt, ...) {
+  std::fprintf(stderr, "[%s] ", level);
+  va_list ap;
+  va_start(ap, fmt);
+  std::vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  std::fputc('\n', stderr);
+}
+} // namespace detail
+using detail::log;
+
+// ---- Shader statics (src/Shader.cpp:7-12) -------------------------------------------------------------------------
+glm::vec3 Shader::ka = glm::vec3(0.005f, 0.005f, 0.005f);
+glm::vec3 Shader::ks = glm::vec3(0.7937, 0.7937, 0.7937);
+float Shader::p = 150;
+float Shader::kh = 0.2;
+float Shader::kn = 0.1;
+
+// ---- TextureLoader (src/TextureLoader.cpp:3-12) -------------------------------------------------------------------
+TextureLoader::TextureLoader(const std::string &path) : m_path(path) {
+  int w = 0, h = 0;
+  detail::load_image_bgr(path, m_bgr, w, h); // throws "Cannot open file: <path>"
+  m_width = (std::size_t)w, m_height = (std::size_t)h;
+}
+TextureLoader::TextureLoader(const uint8_t *bgr, int width, int height) : m_path("<memory>") {
+  if (!bgr || width <= 0 || height <= 0) throw std::runtime_error("Cannot open file: <memory>");
+  m_bgr.assign(bgr, bgr + (size_t)width * height * 3);
+  m_width = (std::size_t)width, m_height = (std::size_t)height;
+}
+
+// ---- Shader (src/Shader.cpp:19-23,94-108) -------------------------------------------------------------------------
+Shader::Shader(const std::string &path) : Shader(std::make_shared<TextureLoader>(path)) {}
+Shader::Shader(std::shared_ptr<TextureLoader> loader) : texture(std::move(loader)) {}
+bool Shader::setFragmentShader(SHADERS_TYPE type) {
+  if (static_cast<std::uint8_t>(type) >= 5) {
+    log("error", "Set FramentShader Error Due To Invalid Shader Type Input!");
+    return false;
+  }
+  m_type = type;
+  return true;
+}
+
+// ---- Object::updateModelMatrix (src/Object.cpp:23-31) -------------------------------------------------------------
+static glm::mat4 make_model(const glm::vec3 &axis, float angle, const glm::vec3 &translation, const glm::vec3 &scale) {
+  auto T = glm::translate(glm::mat4(1.0f), translation);
+  auto R = glm::rotate(glm::mat4(1.0f), glm::radians(angle), axis);
+  auto S = glm::scale(glm::mat4(1.0f), scale);
+  return T * R * S;
+}
+void Object::updateModelMatrix(const glm::vec3 &axis, float angle, const glm::vec3 &translation, const glm::vec3 &scale) {
+  modelMatrix = make_model(axis, angle, translation, scale);
+}
+
+// ---- ObjLoader (src/ObjLoader.cpp) --------------------------------------------------------------------------------
+ObjLoader::ObjLoader(const std::string &path, const std::string &meshName, const glm::mat4x4 &model)
+    : m_path(path), m_meshName(meshName), m_model(model) {}
+ObjLoader::ObjLoader(const std::string &path, const std::string &meshName, const glm::vec3 &axis, float angle,
+                     const glm::vec3 &translation, const glm::vec3 &scale)
+    : ObjLoader(path, meshName) {
+  updateModelMatrix(axis, angle, translation, scale);
+}
+void ObjLoader::updateModelMatrix(const glm::vec3 &axis, float angle, const glm::vec3 &translation, const glm::vec3 &scale) {
+  m_model = make_model(axis, angle, translation, scale);
+}
+
+namespace {
+struct VKey { // equality semantics of Vertex::operator== (float ==, so -0 == +0)
+  float v[11];
+  bool operator==(const VKey &o) const {
+    for (int i = 0; i < 11; ++i)
+      if (!(v[i] == o.v[i])) return false;
+    return true;
+  }
+};
+struct VKeyHash {
+  size_t operator()(const VKey &k) const {
+    size_t seed = 0;
+    for (int i = 0; i < 11; ++i) {
+      float f = k.v[i] == 0.0f ? 0.0f : k.v[i]; // -0 and +0 hash alike
+      uint32_t u;
+      std::memcpy(&u, &f, 4);
+      seed ^= (size_t)u + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+    }
+    return seed;
+  }
+};
+
+// Tools::calculateNormalWithWeight (src/Tools.cpp:234-248)
+glm::vec3 normal_with_weight(const glm::vec3 &pa, const glm::vec3 &pb, const glm::vec3 &pc) {
+  const glm::vec3 AB = pb - pa, AC = pc - pa;
+  glm::vec3 normal = glm::cross(AB, AC);
+  const float length = glm::length(normal);
+  const float arc_sin_degree = length / (glm::length(AB) * glm::length(AC));
+  if (!(-(1e-8) <= length && length <= 1e-8)) normal = normal * (glm::asin(arc_sin_degree) / length);
+  return glm::normalize(normal);
+}
+
+int fix_index(int i, int n) { return i > 0 ? i - 1 : n + i; }
+} // namespace
+
+// tinyobj::LoadObj (triangulate = true) + processingVertexData (src/ObjLoader.cpp:78-233).
+// tinyobjloader is an absent submodule; its documented behaviour is restated: 1-based / negative-relative indices,
+// fan triangulation, missing colours = 1, absent vt / vn → no texcoord / normal.
+std::optional<std::unique_ptr<Mesh>> ObjLoader::startLoadingFromFile(const std::string &objName) {
+  std::ifstream in(m_path);
+  if (!in) {
+    log("error", "[TinyObjReader]: Error Occured! Cannot open file [%s]", m_path.c_str());
+    throw std::runtime_error("LoadObj Error");
+  }
+  std::vector<glm::vec3> pos, col, nrm;
+  std::vector<glm::vec2> tex;
+  struct Corner {
+    int v, t, n;
+  };
+  std::vector<Corner> corners;
+  std::string line, shape_name;
+  while (std::getline(in, line)) {
+    const char *s = line.c_str();
+    while (*s == ' ' || *s == '\t') ++s;
+    if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+      float v[6] = {0, 0, 0, 1, 1, 1};
+      int n = std::sscanf(s + 2, "%f %f %f %f %f %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
+      pos.emplace_back(v[0], v[1], v[2]);
+      col.push_back(n >= 6 ? glm::vec3(v[3], v[4], v[5]) : glm::vec3(1.0f));
+    } else if (s[0] == 'v' && s[1] == 't') {
+      float u = 0, v = 0;
+      std::sscanf(s + 3, "%f %f", &u, &v);
+      tex.emplace_back(u, v);
+    } else if (s[0] == 'v' && s[1] == 'n') {
+      float x = 0, y = 0, z = 0;
+      std::sscanf(s + 3, "%f %f %f", &x, &y, &z);
+      nrm.emplace_back(x, y, z);
+    } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+      std::vector<Corner> poly;
+      std::istringstream ss(s + 2);
+      std::string tok;
+      while (ss >> tok) {
+        Corner c{0, -1, -1};
+        int vi = 0, ti = 0, ni = 0;
+        if (std::sscanf(tok.c_str(), "%d/%d/%d", &vi, &ti, &ni) == 3) {
+          c.t = fix_index(ti, (int)tex.size()), c.n = fix_index(ni, (int)nrm.size());
+        } else if (std::sscanf(tok.c_str(), "%d//%d", &vi, &ni) == 2) {
+          c.n = fix_index(ni, (int)nrm.size());
+        } else if (std::sscanf(tok.c_str(), "%d/%d", &vi, &ti) == 2) {
+          c.t = fix_index(ti, (int)tex.size());
+        } else if (std::sscanf(tok.c_str(), "%d", &vi) != 1) {
+          continue;
+        }
+        c.v = fix_index(vi, (int)pos.size());
+        poly.push_back(c);
+      }
+      for (size_t k = 2; k < poly.size(); ++k) corners.push_back(poly[0]), corners.push_back(poly[k - 1]), corners.push_back(poly[k]);
+    } else if ((s[0] == 'o' || s[0] == 'g') && (s[1] == ' ' || s[1] == '\t')) {
+      shape_name = s + 2;
+    }
+  }
+
+  bool noNormal = true;
+  std::vector<Vertex> vertices;
+  std::vector<uint32_t> indices;
+  std::unordered_map<VKey, uint32_t, VKeyHash> unique;
+  for (const Corner &c : corners) {
+    if (c.v < 0 || c.v >= (int)pos.size()) {
+      log("error", "[TinyObjReader]: Error Occured! vertex index out of range");
+      throw std::runtime_error("LoadObj Error");
+    }
+    Vertex vertex;
+    vertex.position = pos[c.v];
+    vertex.color = col[c.v];
+    if (c.n >= 0 && c.n < (int)nrm.size()) {
+      noNormal = false;
+      vertex.normal = glm::normalize(nrm[c.n]); // (:141-145)
+    }
+    if (c.t >= 0 && c.t < (int)tex.size()) vertex.texCoord = glm::vec2(tex[c.t].x, 1.0f - tex[c.t].y); // (:150-152)
+    VKey k{{vertex.position.x, vertex.position.y, vertex.position.z, vertex.color.x, vertex.color.y, vertex.color.z,
+            vertex.normal.x, vertex.normal.y, vertex.normal.z, vertex.texCoord.x, vertex.texCoord.y}};
+    auto it = unique.find(k);
+    if (it == unique.end()) {
+      it = unique.emplace(k, (uint32_t)vertices.size()).first;
+      vertices.push_back(vertex);
+    }
+    indices.push_back(it->second);
+  }
+  std::vector<glm::uvec3> faces(indices.size() / 3);
+  for (size_t i = 0; i < indices.size() / 3; ++i) {
+    uint32_t a = indices[3 * i], b = indices[3 * i + 1], c = indices[3 * i + 2];
+    faces[i] = glm::uvec3(a, b, c);
+    if (noNormal) { // (:181-188)
+      Vertex &A = vertices[a], &B = vertices[b], &C = vertices[c];
+      A.normal = normal_with_weight(A.position, B.position, C.position);
+      B.normal = normal_with_weight(B.position, C.position, A.position);
+      C.normal = normal_with_weight(C.position, A.position, B.position);
+    }
+  }
+  auto mesh = std::make_unique<Mesh>(objName.empty() ? shape_name : objName, std::move(vertices), std::move(faces));
+  return mesh;
+}
+
+// ---- Scene --------------------------------------------------------------------------------------------------------
+Scene::Scene(const std::string &sceneName, const glm::vec3 &eye, const glm::vec3 &center, const glm::vec3 &up,
+             glm::vec3, std::size_t, float)
+    : m_sceneName(sceneName), m_eye(eye), m_center(center), m_up(up) {
+  setViewMatrix(eye, center, up);
+}
+
+bool Scene::addGraphicObj(const std::string &path, const std::string &meshName, const glm::vec3 &axis, float angle,
+                          const glm::vec3 &translation, const glm::vec3 &scale_) {
+  if (m_loadedObjs.find(meshName) != m_loadedObjs.end()) {
+    log("error", "Add Graphic Obj Error! This Object has already been identified");
+    return false;
+  }
+  m_loadedObjs[meshName].loader = std::make_unique<ObjLoader>(path, meshName, axis, angle, translation, scale_);
+  m_objOrder.push_back(meshName);
+  return true;
+}
+bool Scene::addGraphicObj(const std::string &path, const std::string &meshName) {
+  if (m_loadedObjs.find(meshName) != m_loadedObjs.end()) {
+    log("error", "This Object has already been identified");
+    return false;
+  }
+  m_loadedObjs[meshName].loader = std::make_unique<ObjLoader>(path, meshName);
+  m_objOrder.push_back(meshName);
+  return true;
+}
+bool Scene::addGraphicObj(std::unique_ptr<Object> object, const std::string &objectName) {
+  if (m_loadedObjs.find(objectName) != m_loadedObjs.end()) {
+    log("error", "This Object has already been identified");
+    return false;
+  }
+  m_loadedObjs[objectName].loader = std::nullopt;
+  m_loadedObjs[objectName].mesh = std::move(object);
+  m_objOrder.push_back(objectName);
+  return true;
+}
+
+bool Scene::startLoadingMesh(const std::string &meshName) {
+  auto it = m_loadedObjs.find(meshName);
+  if (it == m_loadedObjs.end()) {
+    log("error", "Start Loading Mesh Failed! Because There is nothing found in m_loadedObjs");
+    return false;
+  }
+  if (it->second.mesh != nullptr) {
+    log("error", "Start Loading Mesh Failed! Because %s Has Already Loaded into m_loadedObjs", meshName.c_str());
+    return false;
+  }
+  try {
+    if (!it->second.loader.has_value()) return false;
+    ObjLoader &ld = *it->second.loader.value();
+    auto mesh_op = ld.startLoadingFromFile(meshName);
+    if (!mesh_op.has_value()) {
+      log("error", "Start Loading Mesh Failed! Because Loading Internel Error!");
+      return false;
+    }
+    it->second.mesh = std::move(mesh_op.value());
+  } catch (const std::exception &e) {
+    log("error", "Start Loading Mesh Failed! Reason: %s", e.what());
+    return false;
+  }
+  return true;
+}
+
+std::optional<std::shared_ptr<Object>> Scene::getMeshObj(const std::string &meshName) {
+  auto it = m_loadedObjs.find(meshName);
+  if (it == m_loadedObjs.end()) {
+    log("error", "Get Mesh Failed! Because There is nothing found in m_loadedObjs");
+    return std::nullopt;
+  }
+  if (it->second.mesh == nullptr) {
+    log("error", "You Have to get Mesh Object After Deploy startLoadingMesh");
+    return std::nullopt;
+  }
+  return std::shared_ptr<Object>(it->second.mesh.get(), [](Object *) {});
+}
+
+bool Scene::addShader(const std::string &shaderName, const std::string &texturePath, SHADERS_TYPE type) {
+  if (m_shaders.find(shaderName) != m_shaders.end()) {
+    log("error", "Add Shader Failed! Because Shader %s Already Exist!", shaderName.c_str());
+    return false;
+  }
+  try {
+    auto sh = std::make_shared<Shader>(texturePath);
+    sh->setFragmentShader(type);
+    m_shaders[shaderName] = sh;
+  } catch (const std::exception &e) {
+    log("error", "Add Shader Failed! Reason: %s", e.what());
+    return false;
+  }
+  return true;
+}
+bool Scene::addShader(const std::string &shaderName, std::shared_ptr<TextureLoader> text, SHADERS_TYPE type) {
+  if (m_shaders.find(shaderName) != m_shaders.end()) {
+    log("error", "Add Shader Failed! Because Shader %s Already Exist!", shaderName.c_str());
+    return false;
+  }
+  auto sh = std::make_shared<Shader>(std::move(text));
+  sh->setFragmentShader(type);
+  m_shaders[shaderName] = sh;
+  return true;
+}
+
+bool Scene::bindShader2Mesh(const std::string &meshName, const std::string &shaderName) {
+  auto it = m_loadedObjs.find(meshName);
+  if (it == m_loadedObjs.end()) {
+    log("error", "Bind Shader To Mesh Failed! Because Loaded Mesh %s Not found!", meshName.c_str());
+    return false;
+  }
+  auto sh = m_shaders.find(shaderName);
+  if (sh == m_shaders.end()) {
+    log("error", "Bind Shader To Mesh Failed! Because Shader %s Not found!", shaderName.c_str());
+    return false;
+  }
+  if (!it->second.mesh) { // the reference dereferences a null mesh here; we report instead
+    log("error", "Bind Shader To Mesh Failed! Because Mesh %s Is Not Loaded Yet!", meshName.c_str());
+    return false;
+  }
+  it->second.mesh->bindShader2Mesh(sh->second);
+  return true;
+}
+
+void Scene::addLight(std::string name, std::shared_ptr<light_struct> light) {
+  for (auto &kv : m_lights)
+    if (kv.first == name) {
+      log("warn", "Add Light Success! Because Light %s Already Been Added!", name.c_str());
+      return;
+    }
+  m_lights.emplace_back(std::move(name), std::move(light));
+}
+void Scene::addLights(std::vector<std::pair<std::string, std::shared_ptr<light_struct>>> lights) {
+  for (auto &kv : lights) addLight(kv.first, kv.second);
+}
+
+bool Scene::setModelMatrix(const std::string &meshName, const glm::vec3 &axis, float angle, const glm::vec3 &translation,
+                           const glm::vec3 &scale_) {
+  auto it = m_loadedObjs.find(meshName);
+  if (it == m_loadedObjs.end() || !it->second.mesh) {
+    log("error", "Editing Model Matrix Failed! Because %s Not Found", meshName.c_str());
+    return false;
+  }
+  it->second.mesh->updateModelMatrix(axis, angle, translation, scale_);
+  return true;
+}
+
+// (src/Scene.cpp:263-271)
+void Scene::setViewMatrix(const glm::vec3 &eye, const glm::vec3 &center, const glm::vec3 &up) {
+  m_eye = eye, m_center = center, m_up = up;
+  m_view = glm::lookAtLH(eye, center, up);
+}
+// (src/Scene.cpp:273-294) — fovy is handed to a RADIANS api as-is, exactly like the reference
+void Scene::setProjectionMatrix(float fovy, float zNear, float zFar) {
+  m_fovy = fovy, m_near = zNear, m_far = zFar;
+  scale = (m_far - m_near) / 2.0f;
+  offset = (m_far + m_near) / 2.0f;
+  m_projection = glm::perspectiveLH_NO(fovy, m_aspectRatio, zNear, zFar);
+}
+// (src/Scene.cpp:314-335)
+void Scene::setNDCMatrix(std::size_t width, std::size_t height) {
+  m_width = width, m_height = height;
+  if (!m_height) throw std::runtime_error("Height cannot be zero!");
+  m_aspectRatio = static_cast<float>(m_width) / static_cast<float>(m_height);
+  glm::mat4 matrix(1.0f);
+  matrix[0][0] = width / 2.0f * m_aspectRatio;
+  matrix[1][1] = height / 2.0f;
+  matrix[3][0] = width / 2.0f;
+  matrix[3][1] = height / 2.0f;
+  m_ndcToScreenMatrix = matrix;
+}
+
+// (src/Scene.cpp:296-312)
+std::vector<light_struct> Scene::loadLights() {
+  if (reference_exact_lights) return std::vector<light_struct>(m_lights.size()); // as written: default lights
+  std::vector<light_struct> res;
+  for (auto &kv : m_lights) res.push_back(*kv.second);
+  return res;
+}
+
+static inline glm::vec3 to_vec3(const glm::vec4 &v) { return glm::vec3(v.x / v.w, v.y / v.w, v.z / v.w); } // src/Tools.cpp:74-76
+
+// (src/Scene.cpp:903-964)
+std::vector<Scene::ObjTuple> Scene::loadTriangleStream() {
+  std::vector<ObjTuple> stream;
+  for (const std::string &name : m_objOrder) {
+    const ObjInfo &obj = m_loadedObjs[name];
+    if (!obj.mesh) continue;
+    const auto &mesh = obj.mesh;
+    const glm::mat4 &modelMatrix = mesh->getModelMatrix();
+    const glm::mat4 NDC_MVP = m_ndcToScreenMatrix * m_projection * m_view * modelMatrix;
+    const glm::mat4 Normal_M = glm::transpose(glm::inverse(modelMatrix));
+    const auto &faces = mesh->getFaces();
+    const auto &verts = mesh->getVertices();
+    std::vector<RasterTriangle> ret(faces.size());
+    for (size_t fi = 0; fi < faces.size(); ++fi) {
+      const glm::uvec3 &face = faces[fi];
+      const unsigned idx[3] = {face.x, face.y, face.z};
+      for (int k = 0; k < 3; ++k) {
+        const Vertex &V = verts[idx[k]];
+        glm::vec3 P = to_vec3(NDC_MVP * glm::vec4(V.position, 1.0f));
+        P.z = P.z * scale + offset; // Z-Depth
+        glm::vec3 N = to_vec3(Normal_M * glm::vec4(V.normal, 1.0f));
+        ret[fi].pos[k][0] = P.x, ret[fi].pos[k][1] = P.y, ret[fi].pos[k][2] = P.z;
+        ret[fi].nrm[k][0] = N.x, ret[fi].nrm[k][1] = N.y, ret[fi].nrm[k][2] = N.z;
+        ret[fi].uv[k][0] = V.texCoord.x, ret[fi].uv[k][1] = V.texCoord.y;
+      }
+    }
+    stream.emplace_back(mesh->shader(), std::move(ret));
+  }
+  return stream;
+}
+
+// ---- RenderingPipeline (src/Render.cpp) ---------------------------------------------------------------------------
+RenderingPipeline::RenderingPipeline() : RenderingPipeline(800, 600) {}
+RenderingPipeline::RenderingPipeline(std::size_t width, std::size_t height) : m_width(width), m_height(height) {
+  for (auto &c : m_channels) c.resize(width * height);
+  m_zBuffer.resize(width * height);
+  m_frameBuffer8.resize(width * height * 3);
+  clear(Buffers::Color | Buffers::Depth);
+}
+RenderingPipeline::~RenderingPipeline() {}
+void RenderingPipeline::clearFrameBuffer() {
+  for (auto &c : m_channels) std::fill(c.begin(), c.end(), 0.0f);
+}
+void RenderingPipeline::clearZDepth() { std::fill(m_zBuffer.begin(), m_zBuffer.end(), std::numeric_limits<float>::infinity()); }
+void RenderingPipeline::clear(Buffers flags) {
+  const bool c = (flags & Buffers::Color) == Buffers::Color, d = (flags & Buffers::Depth) == Buffers::Depth;
+  if (c) clearFrameBuffer();
+  if (d) clearZDepth();
+  m_justCleared = c && d;
+}
+bool RenderingPipeline::addScene(std::shared_ptr<Scene> scene, std::optional<std::string> name) {
+  try {
+    if (scene == nullptr) return false;
+    if (name.has_value()) scene->m_sceneName = name.value();
+    scene->setNDCMatrix(m_width, m_height);
+    for (auto &kv : m_scenes)
+      if (kv.first == scene->m_sceneName) {
+        log("error", "Add Scene Failed! Scene Already Exist");
+        return false;
+      }
+    m_scenes.emplace_back(scene->m_sceneName, scene);
+  } catch (const std::exception &e) {
+    log("error", "Add Scene Failed! Reason: %s", e.what());
+    return false;
+  }
+  return true;
+}
+// (src/Render.cpp:57-64): draw, cv::merge, convertTo(CV_8UC3) = saturate_cast<uchar>(cvRound(v)); no imshow here
+void RenderingPipeline::display(Primitive type) {
+  draw(type);
+  const size_t n = m_width * m_height;
+  for (size_t i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c) {
+      float v = m_channels[c][i];
+      long r = (v == v && v > -1e9f && v < 1e9f) ? std::lrintf(v) : (v > 0 ? 255 : 0);
+      m_frameBuffer8[i * 3 + c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+// ---- TraditionalRasterizer (src/Rasterizer.cpp:183-240) -----------------------------------------------------------
+TraditionalRasterizer::TraditionalRasterizer() : RenderingPipeline() { init(); }
+TraditionalRasterizer::TraditionalRasterizer(std::size_t width, std::size_t height) : RenderingPipeline(width, height) { init(); }
+void TraditionalRasterizer::init() {
+  int dev = 0;
+  if (const char *e = std::getenv("SRZ_DEVICE")) dev = std::atoi(e);
+  int rc = srz_create(&m_ctx, dev);
+  if (rc != SRZ_OK) throw std::runtime_error(std::string("TraditionalRasterizer: ") + srz_last_error(nullptr));
+}
+TraditionalRasterizer::~TraditionalRasterizer() { srz_destroy(m_ctx); }
+
+void TraditionalRasterizer::draw(Primitive type) {
+  if ((type != Primitive::LINES) && (type != Primitive::TRIANGLES)) {
+    log("error", "Primitive Type is not supported!");
+    throw std::runtime_error("Primitive Type is not supported!");
+  }
+  const int prim = type == Primitive::LINES ? SRZ_PRIMITIVE_LINES : SRZ_PRIMITIVE_TRIANGLES;
+  last_stats = Stats();
+  bool fused = m_justCleared;
+  m_justCleared = false;
+  for (auto &kv : m_scenes) {
+    Scene &scene = *kv.second;
+    std::vector<Scene::ObjTuple> stream = scene.loadTriangleStream();
+    std::vector<light_struct> lights = scene.loadLights();
+    const glm::vec3 eye = scene.loadEyeVec();
+
+    std::vector<srz_light> L(lights.size());
+    for (size_t i = 0; i < lights.size(); ++i) {
+      L[i].pos[0] = lights[i].position.x, L[i].pos[1] = lights[i].position.y, L[i].pos[2] = lights[i].position.z;
+      L[i].intensity[0] = lights[i].intensity.x, L[i].intensity[1] = lights[i].intensity.y, L[i].intensity[2] = lights[i].intensity.z;
+    }
+    std::vector<srz_batch> B;
+    for (auto &tup : stream) {
+      const std::shared_ptr<Shader> &sh = std::get<0>(tup);
+      const std::vector<RasterTriangle> &tris = std::get<1>(tup);
+      if (tris.empty()) continue;
+      if (!sh) throw std::runtime_error("draw: a mesh with triangles has no shader bound (bindShader2Mesh)"); // D14
+      srz_batch b{};
+      b.shader = (int)sh->type();
+      b.tex_id = -1;
+      b.n_tris = (uint32_t)tris.size();
+      b.tris = reinterpret_cast<const srz_tri *>(tris.data());
+      const bool needs_tex = sh->type() == SHADERS_TYPE::TEXTURE || sh->type() == SHADERS_TYPE::DISPLACEMENT || sh->type() == SHADERS_TYPE::BUMP;
+      if (needs_tex) {
+        TextureLoader *tl = sh->getTextureObject().get();
+        auto it = m_texSlots.find(tl);
+        if (it == m_texSlots.end()) {
+          int slot = (int)m_texSlots.size();
+          if (slot >= 64) throw std::runtime_error("draw: more than 64 distinct textures");
+          int rc = srz_texture_upload(m_ctx, slot, tl->bgr().data(), (int)tl->width(), (int)tl->height(), (int)tl->width() * 3);
+          if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+          it = m_texSlots.emplace(tl, slot).first;
+          m_texOwners.push_back(sh->getTextureObject()); // keep the key's identity stable
+        }
+        b.tex_id = it->second;
+      }
+      B.push_back(b);
+    }
+    srz_frame fr{};
+    fr.width = (int)m_width, fr.height = (int)m_height;
+    fr.eye[0] = eye.x, fr.eye[1] = eye.y, fr.eye[2] = eye.z;
+    fr.ka[0] = Shader::ka.x, fr.ka[1] = Shader::ka.y, fr.ka[2] = Shader::ka.z;
+    fr.ks[0] = Shader::ks.x, fr.ks[1] = Shader::ks.y, fr.ks[2] = Shader::ks.z;
+    fr.p = Shader::p, fr.kh = Shader::kh, fr.kn = Shader::kn;
+    fr.n_lights = (uint32_t)L.size(), fr.lights = L.data();
+    fr.n_batches = (uint32_t)B.size(), fr.batches = B.data();
+    fr.flags = SRZ_EXACT_SPLIT | (fused ? SRZ_FUSED_CLEAR : 0u);
+    fused = false; // only the first scene after clear() may skip reading the framebuffer
+    srz_stats st{};
+    int rc = srz_draw(m_ctx, prim, &fr, m_zBuffer.data(), m_channels[0].data(), m_channels[1].data(), m_channels[2].data(),
+                      collect_stats ? &st : nullptr);
+    if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+    last_stats.n_tris += st.n_tris, last_stats.n_culled += st.n_culled, last_stats.pixel_tests += st.pixel_tests;
+    last_stats.fragments += st.fragments, last_stats.shaded += st.shaded, last_stats.visible += st.visible;
+    last_stats.visible_textured += st.visible_textured;
+  }
+}
+
+} // namespace SoftRasterizer

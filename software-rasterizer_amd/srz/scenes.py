@@ -1,0 +1,100 @@
+"""The five BASELINE.json workloads, built with the PRODUCT's host layer (libsrz_host.so).
+
+Frame index → rotation angle deg = 10*frame mod 360 (the ±10° steps of the reference's main loop, src/main.cpp:164-168);
+camera / projection / lights / model placement are the README's (README.md:142-198) and src/main.cpp:150-159.
+"""
+import os
+
+import numpy as np
+
+from . import abi, host
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SPOT_OBJ = os.path.join(REPO, "assets/models/spot/spot_triangulated_good.obj")
+SPOT_TEX = os.path.join(REPO, "assets/models/spot/spot_texture.png")
+BUNNY_OBJ = os.path.join(REPO, "assets/models/bunny/bunny.obj")
+
+EYE = (0.0, 0.0, 0.9)
+L1 = ((0.9, 0.9, -0.9), (100, 100, 100))
+L2 = ((0.0, 0.8, 0.9), (50, 50, 50))
+Y = (0, 1, 0)
+
+
+class Workload:
+    """A host Scene plus the per-frame model-matrix recipe; frame(i) returns an abi.Frame (post-MVP stream)."""
+
+    def __init__(self, name, width, height, meshes):
+        """meshes: list of (mesh_name, obj_path, shader_type, translation, scale)."""
+        self.name, self.width, self.height, self.meshes = name, width, height, meshes
+        sc = host.Scene(name, EYE, (0, 0, 0), Y, width, height)
+        textured = {}
+        for (mname, path, shader, t, s) in meshes:
+            sc.add_obj(path, mname, Y, 0.0, t, (s, s, s))
+            sname = f"shader{int(shader)}"
+            if sname not in textured:
+                # every Shader needs a loadable image in the reference, NORMAL / PHONG included (src/Scene.cpp:158)
+                sc.add_shader(sname, SPOT_TEX, shader)
+                textured[sname] = True
+            sc.bind(mname, sname)
+        sc.add_light("Light1", *L1)
+        sc.add_light("Light2", *L2)
+        self.scene = sc
+        self.textures = {}  # id(ndarray) -> slot
+        self.texture_arrays = []
+
+    def _slot(self, tex):
+        if tex is None:
+            return -1
+        k = id(tex)
+        if k not in self.textures:
+            self.textures[k] = len(self.texture_arrays)
+            self.texture_arrays.append(tex)
+        return self.textures[k]
+
+    def frame(self, frame_idx, flags=abi.FUSED_CLEAR):
+        deg = float((10 * frame_idx) % 360)
+        sc = self.scene
+        for (mname, _, _, t, s) in self.meshes:
+            sc.set_model(mname, Y, deg, t, (s, s, s))
+        sc.set_view(EYE, (0, 0, 0), Y)
+        sc.set_projection(45.0, 0.1, 100.0)  # raw 45 into a radians API, as the reference does (src/main.cpp:156-159)
+        batches = []
+        for (shader, tex, tris) in sc.stream():
+            needs = shader in (abi.SHADER_TEXTURE, abi.SHADER_DISPLACEMENT, abi.SHADER_BUMP)
+            batches.append((shader, self._slot(tex) if needs else -1, tris))
+        ka, ks, p, kh, kn = host.shader_constants()
+        return abi.Frame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), batches, flags, ka, ks, p, kh, kn)
+
+    def upload_textures(self, ctx):
+        for slot, tex in enumerate(self.texture_arrays):
+            ctx.texture_upload(slot, tex)
+
+
+def spot_texture_1024(shader=abi.SHADER_TEXTURE, size=1024):
+    """configs[1]: spot_triangulated_good.obj, 1024x1024, TEXTURE shader + 2 point lights."""
+    return Workload("spot_texture_1024", size, size, [("spot", SPOT_OBJ, shader, (0, 0, 0), 0.3)])
+
+
+def spot_bunny_1080p():
+    """configs[2]: spot + bunny, 1920x1080, Blinn-Phong, 2 lights."""
+    return Workload("spot_bunny_phong_1080p", 1920, 1080,
+                    [("spot", SPOT_OBJ, abi.SHADER_PHONG, (-0.25, 0, 0), 0.3),
+                     ("bunny", BUNNY_OBJ, abi.SHADER_PHONG, (0.3, -0.2, 0), 2.0)])
+
+
+def spot_grid16_2048():
+    """configs[3]: spot x16 (4x4 grid, s=0.1), 2048x2048, TEXTURE."""
+    meshes = [(f"spot_{i}{j}", SPOT_OBJ, abi.SHADER_TEXTURE, (-0.375 + 0.25 * i, -0.375 + 0.25 * j, 0.0), 0.1)
+              for i in range(4) for j in range(4)]
+    return Workload("spot_x16_texture_2048", 2048, 2048, meshes)
+
+
+def spot_overdraw8_4096():
+    """configs[4]: 8 depth-stacked spots submitted far-to-near, NORMAL / PHONG alternating, 4096x4096."""
+    meshes = [(f"spot_{k}", SPOT_OBJ, abi.SHADER_NORMAL if k % 2 == 0 else abi.SHADER_PHONG, (0, 0, 0.05 * k), 0.3)
+              for k in range(8)]
+    return Workload("spot_x8_overdraw_4096", 4096, 4096, meshes)
+
+
+WORKLOADS = {"spot_texture_1024": spot_texture_1024, "spot_bunny_phong_1080p": spot_bunny_1080p,
+             "spot_x16_texture_2048": spot_grid16_2048, "spot_x8_overdraw_4096": spot_overdraw8_4096}
