@@ -71,7 +71,7 @@ def main():
     import torch
     import torch.distributed as dist
     import srz
-    from srz import abi, scenes
+    from srz import abi, parallel, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -115,10 +115,8 @@ def main():
     def step():
         fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
             # band b = local_band*world + rank  →  row-major planes (rows beyond `height` are all-gather padding)
-            full.view(n_frames, 4, bpr, world, 32, fs.width).copy_(
-                gathered.view(world, n_frames, 4, bpr, 32, fs.width).permute(1, 2, 3, 0, 4, 5))
+            parallel.all_gather_frames(out, world, gathered, full)
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,58 @@
+// api_demo.cpp — the reference's documented rasterizer usage (README.md:127-205 of Liupeter01/Software-Rasterizer),
+// written against OUR headers.  Exit codes: 0 ok, 3 = no GPU (constructor threw), 1 = wrong output.
+#include <SoftRasterizer.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+int main(int argc, char **argv) {
+  const std::string home = (argc > 1 ? std::string(argv[1]) : std::string(".")) + "/assets/";
+  try {
+    auto render = std::make_shared<SoftRasterizer::TraditionalRasterizer>(256, 256);
+    auto scene = std::make_shared<SoftRasterizer::Scene>("TestScene", glm::vec3(0.0f, 0.0f, 0.9f), glm::vec3(0.0f, 0.0f, 0.0f),
+                                                         glm::vec3(0.0f, 1.0f, 0.0f));
+    float degree = 30.0f;
+    if (!scene->addGraphicObj(home + "models/spot/spot_triangulated_good.obj", "spot", glm::vec3(0, 1, 0), degree,
+                              glm::vec3(0.f, 0.0f, 0.0f), glm::vec3(0.3f, 0.3f, 0.3f)))
+      return 1;
+    if (!scene->addShader("spot_shader", home + "models/spot/spot_texture.png", SoftRasterizer::SHADERS_TYPE::TEXTURE)) return 1;
+    if (!scene->startLoadingMesh("spot")) return 1;
+    if (!scene->bindShader2Mesh("spot", "spot_shader")) return 1;
+    auto light1 = std::make_shared<SoftRasterizer::light_struct>();
+    light1->position = glm::vec3{0.9, 0.9, -0.9f};
+    light1->intensity = glm::vec3{100, 100, 100};
+    auto light2 = std::make_shared<SoftRasterizer::light_struct>();
+    light2->position = glm::vec3{0.f, 0.8f, 0.9f};
+    light2->intensity = glm::vec3{50, 50, 50};
+    scene->addLight("Light1", light1);
+    scene->addLight("Light2", light2);
+    if (!render->addScene(scene)) return 1;
+    if (render->addScene(scene)) return 1; // duplicate → false
+
+    render->clear(SoftRasterizer::Buffers::Color | SoftRasterizer::Buffers::Depth);
+    scene->setModelMatrix("spot", glm::vec3(0.f, 1.f, 0.f), degree, glm::vec3(0.0f), glm::vec3(0.3f));
+    scene->setViewMatrix(glm::vec3(0.0f, 0.0f, 0.9f), glm::vec3(0.0f, 0.0f, 0.0f), glm::vec3(0.0f, 1.0f, 0.0f));
+    scene->setProjectionMatrix(45.0f, 0.1f, 100.0f);
+    render->collect_stats = true;
+    render->display(SoftRasterizer::Primitive::TRIANGLES);
+
+    size_t covered = 0;
+    for (float z : render->zBuffer()) covered += std::isfinite(z) ? 1 : 0;
+    std::printf("covered=%zu fragments=%llu visible=%llu\n", covered, (unsigned long long)render->last_stats.fragments,
+                (unsigned long long)render->last_stats.visible);
+    if (covered == 0 || covered != render->last_stats.visible) return 1;
+    bool threw = false;
+    try {
+      render->draw(static_cast<SoftRasterizer::Primitive>(7));
+    } catch (const std::runtime_error &e) {
+      threw = std::string(e.what()) == "Primitive Type is not supported!";
+    }
+    return threw ? 0 : 1;
+  } catch (const std::runtime_error &e) {
+    std::fprintf(stderr, "runtime_error: %s\n", e.what());
+    return 3;
+  }
+}

@@ -1,0 +1,56 @@
+"""not-gpu: the oracle against the committed golden fixtures (tests/golden/make_golden.py generated them from the
+oracle itself — the reference holds none; they pin the oracle against regressions, not against the reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+SAMPLES = np.load(os.path.join(HERE, "golden", "golden_samples.npz"))
+
+
+def check_against_golden(name, planes, stats=None, exact=True):
+    """Shared with the GPU tests: compare planes with the fixture `name`."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = GOLD[name]
+    s = SAMPLES[name]
+    z, c0, c1, c2 = planes
+    xs, ys = s[:, 0].astype(int), s[:, 1].astype(int)
+    assert np.array_equal(z[ys, xs].view(np.uint32), s[:, 2]), "sampled z differs"
+    for k, p in enumerate((c0, c1, c2)):
+        got = p[ys, xs]
+        want = s[:, 3 + k].view(np.float32)
+        if exact:
+            assert np.array_equal(got.view(np.uint32), s[:, 3 + k]), f"sampled c{k} differs"
+        else:
+            assert np.abs(got - want).max() <= 0.5
+    assert int(np.isfinite(z).sum()) == g["covered"]
+    assert make_golden.digest(z) == g["sha256"]["z"]
+    if exact:
+        for k, p in zip(("c0", "c1", "c2"), (c0, c1, c2)):
+            assert make_golden.digest(p) == g["sha256"][k]
+    if stats is not None:
+        assert stats == g["stats"]
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_oracle_reproduces_golden(orc, name):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    f = make_golden.CASES[name]()
+    rc, planes, st = orc.draw(f)
+    assert rc == 0
+    check_against_golden(name, planes, st)
+    assert make_golden.digest(orc.resolve8(planes)) == GOLD[name]["sha256"]["bgr8"]
+
+
+def test_golden_sanity():
+    g = GOLD["config2_1024_f0"]["stats"]
+    # the survey's independent estimate: ~0.43 M pixel tests, ~0.14 M fragments, 2.6 k visible triangles at deg = 0
+    assert 0.40e6 < g["pixel_tests"] < 0.46e6 and 0.13e6 < g["fragments"] < 0.15e6
+    assert 2500 < g["n_tris"] - g["n_culled"] < 2700

@@ -1,0 +1,122 @@
+"""-m gpu: the throughput path (frames resident in HBM, one launch set per batch) and the band sharding, all through
+the C ABI.  A single GPU can play every rank of an N-GPU job, so the sharded outputs are checked here row by row."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from srz import abi, parallel
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    return [scenes.config2(i, size=512) for i in (0, 3, 7, 12, 30)]
+
+
+def render(ctx, frames, flags=abi.FUSED_CLEAR, out=None):
+    fs = ctx.frameset(frames)
+    if out is None:
+        out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+    fs.render(out.data_ptr(), fs.out_bytes, flags, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return fs, out
+
+
+def test_frameset_equals_per_frame_draw_and_oracle(orc, frames):
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    fs, out = render(ctx, frames)
+    got = out.cpu().numpy()
+    tot = {}
+    for i, f in enumerate(frames):
+        rc, ref, st = orc.draw(f)
+        for p in range(4):
+            assert np.array_equal(bits(got[i, p]), bits(ref[p])), (i, p)
+        for k, v in st.items():
+            tot[k] = tot.get(k, 0) + v
+    assert fs.stats() == tot
+    # algorithmic bytes = 16*W*H + 96*N_tri + 24*N_lights + min(3*texW*texH, 3*textured pixels), per frame
+    expect = sum(16 * 512 * 512 + 96 * f.n_tris + 24 * 2 for f in frames) + min(5 * 3 * 1024 * 1024, 3 * tot["visible_textured"])
+    assert fs.algorithmic_bytes() == expect
+    ctx.close()
+
+
+def test_kernel_timing_api(frames):
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    fs = ctx.frameset(frames)
+    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    ctx.set_kernel_timing(True)
+    for _ in range(3):
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+    kt = ctx.kernel_time_ms()
+    assert kt["launches"] == 3 and kt["total_ms"] > 0 and kt["raster_ms"] > 0
+    assert abs(kt["bin_ms"] + kt["raster_ms"] + kt["shade_ms"] - kt["total_ms"]) < 0.2 * kt["total_ms"] + 0.05
+    ctx.close()
+
+
+def test_frameset_argument_checks(frames):
+    import srz
+    ctx = srz.Context(0)
+    with pytest.raises(srz.SrzError):
+        ctx.frameset([scenes.config2(0, size=512), scenes.config2(0, size=256)])     # mixed sizes
+    fs = ctx.frameset(frames[:1])
+    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    with pytest.raises(srz.SrzError) as e:                                           # texture slot 0 never uploaded
+        fs.render(out.data_ptr(), fs.out_bytes)
+    assert e.value.code == abi.SRZ_E_TEXTURE
+    ctx.texture_upload(0, scenes.spot_texture())
+    with pytest.raises(srz.SrzError):
+        fs.render(out.data_ptr(), fs.out_bytes - 4)                                  # buffer too small
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 512, 512), (3, 320, 200), (8, 256, 1080)])
+def test_band_sharding_every_rank_on_one_gpu(orc, world, w, h):
+    """Each rank's shard holds exactly its bands of the oracle frame; all-gather layout + de-interleave rebuild it."""
+    import srz
+    fr = [scenes.config2(i, size=w) if w == h else scenes.config3(i, w, h) for i in (2, 9)]
+    refs = [np.stack(orc.draw(f)[1]) for f in fr]
+    shards = []
+    for rank in range(world):
+        ctx = srz.Context(0, rank, world)
+        ctx.texture_upload(0, scenes.spot_texture())
+        fs, out = render(ctx, fr)
+        lay = parallel.shard_layout(h, rank, world)
+        assert fs.local_rows == lay["local_rows"] and tuple(out.shape) == (2, 4, lay["local_rows"], w)
+        host = out.cpu().numpy()
+        for (lb, band, r0, r1) in parallel.band_rows(h, rank, world):
+            for i in range(2):
+                assert np.array_equal(bits(host[i, :, lb * 32: lb * 32 + (r1 - r0)]), bits(refs[i][:, r0:r1])), (rank, band)
+        shards.append(out.cpu())
+        ctx.close()
+    full = parallel.deinterleave(torch.stack(shards), world).numpy()[:, :, :h]
+    for i in range(2):
+        assert np.array_equal(bits(full[i]), bits(refs[i]))
+
+
+def test_full_size_properties_config2_batch():
+    """At BASELINE's full size with a 36-frame batch: determinism, frame independence, and a checksum of checksums."""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    fr = [scenes.config2(i) for i in range(36)]
+    fs, out = render(ctx, fr)
+    a = out.clone()
+    fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), out.view(torch.int32))                  # deterministic
+    fs2, out2 = render(ctx, list(reversed(fr)))
+    assert torch.equal(out2.flip(0).view(torch.int32), a.view(torch.int32))         # frames are independent of batch order
+    cov = torch.isfinite(a[:, 0]).sum(dim=(1, 2)).cpu().numpy()
+    st = fs.stats()
+    assert int(cov.sum()) == st["visible"] and (cov > 90_000).all() and (cov < 200_000).all()
+    ctx.close()

@@ -1,0 +1,284 @@
+"""not-gpu: hand-derived known-answer tests that pin the CPU oracle to the reference's semantics
+(SURVEY.md §8a "two semantics" table and Appendix B).  The reference holds no fixtures of its own (parity unpinned)."""
+import numpy as np
+import pytest
+
+from srz import abi
+
+F32 = np.float32
+
+
+def tri(a, b, c, z=50.0, nrm=(0, 0, -1), uv=((0, 0), (0, 0), (0, 0))):
+    t = np.zeros(1, abi.TRI_DTYPE)
+    za, zb, zc = (z, z, z) if np.isscalar(z) else z
+    t["pos"][0] = [[a[0], a[1], za], [b[0], b[1], zb], [c[0], c[1], zc]]
+    t["nrm"][0] = [nrm] * 3 if np.ndim(nrm) == 1 else nrm
+    t["uv"][0] = uv
+    return t
+
+
+def frame(tris, w=64, h=64, shader=abi.SHADER_NORMAL, eye=(0, 0, 1), lights=(), flags=abi.FUSED_CLEAR, tex=-1, **kw):
+    batches = tris if isinstance(tris, list) else [(shader, tex, tris)]
+    return abi.Frame(w, h, eye, np.asarray(lights, np.float32).reshape(-1, 2, 3), batches, flags, **kw)
+
+
+# ---------------------------------------------------------------------------------------------- matrices (glm)
+def test_perspective_lh_no_with_raw_45(orc):
+    p = orc.perspective_lh_no(45.0, 1.0, 0.1, 100.0).reshape(4, 4)  # [col][row]
+    th = np.tan(F32(45.0) / F32(2.0), dtype=F32)
+    assert abs(float(th) - 0.5578) < 2e-3  # tan(22.5 rad): the fovy-in-degrees quirk (src/Scene.cpp:293)
+    assert p[0, 0] == F32(1.0) / (F32(1.0) * th) and p[1, 1] == F32(1.0) / th
+    assert p[2, 2] == (F32(100.0) + F32(0.1)) / (F32(100.0) - F32(0.1))
+    assert p[2, 3] == 1.0 and p[3, 2] == -(F32(2.0) * F32(100.0) * F32(0.1)) / (F32(100.0) - F32(0.1))
+    assert p[3, 3] == 0.0 and np.count_nonzero(p) == 5
+
+
+def test_look_at_lh(orc):
+    v = orc.look_at_lh((0, 0, 0.9), (0, 0, 0), (0, 1, 0)).reshape(4, 4)
+    # f=(0,0,-1), s=cross(up,f)=(-1,0,0), u=cross(f,s)=(0,1,0); translation = (-s.e, -u.e, -f.e) = (0,0,0.9)
+    expect = np.array([[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0], [0, 0, F32(0.9), 1]], F32)
+    assert np.array_equal(v, expect)  # -0.0 == 0.0
+
+
+def test_ndc_matrix_stretches_x_by_aspect(orc):
+    n = orc.ndc_matrix(1920, 1080).reshape(4, 4)
+    aspect = F32(1920) / F32(1080)
+    assert n[0, 0] == F32(960.0) * aspect and n[1, 1] == 540.0 and n[3, 0] == 960.0 and n[3, 1] == 540.0
+    assert n[2, 2] == 1.0 and n[3, 3] == 1.0
+
+
+def test_model_matrix_is_T_R_S(orc):
+    m = orc.model_matrix((0, 1, 0), 90.0, (1, 2, 3), (2, 2, 2)).reshape(4, 4).astype(np.float64)
+    # rotate 90 deg about +y (glm::rotate): x-axis -> -z, z-axis -> +x ; scale 2 ; translate
+    expect = np.array([[0, 0, -2, 0], [0, 2, 0, 0], [2, 0, 0, 0], [1, 2, 3, 1]], np.float64)
+    assert np.allclose(m, expect, atol=2e-7)
+
+
+def test_inverse_and_mul(orc):
+    m = orc.model_matrix((1, 2, 3), 37.0, (0.3, -0.2, 0.5), (0.3, 0.4, 0.5))
+    prod = orc.m4_mul(m, orc.m4_inverse(m)).reshape(4, 4)
+    assert np.allclose(prod, np.eye(4), atol=1e-5)
+    t = orc.m4_transpose(m).reshape(4, 4)
+    assert np.array_equal(t, m.reshape(4, 4).T)
+    v = orc.m4_mulv(m, (1, 2, 3, 1))
+    ref = m.reshape(4, 4).T.astype(np.float64) @ np.array([1, 2, 3, 1.0])
+    assert np.allclose(v, ref, rtol=1e-6)
+
+
+def test_vertex_stage_depth_remap_and_normal_w(orc):
+    verts = np.array([[0, 0, 0, 0, 0, 1, 0.25, 0.75], [1, 0, 0, 0, 0, 1, 0, 0], [0, 1, 0, 0, 0, 1, 0, 0]], F32)
+    faces = np.array([[0, 1, 2]], np.uint32)
+    W = H = 256
+    view = orc.look_at_lh((0, 0, 0.9), (0, 0, 0), (0, 1, 0))
+    proj = orc.perspective_lh_no(45.0, 1.0, 0.1, 100.0)
+    model = orc.model_matrix((0, 1, 0), 0.0, (0, 0, 0), (1, 1, 1))
+    t = orc.vertex_stage(verts, faces, model, view, proj, orc.ndc_matrix(W, H), 0.1, 100.0)[0]
+    # origin maps to the screen centre; z_view = 0.9 → NDC z = (A*0.9+B)/0.9, remapped to [near,far]
+    assert t["pos"][0][0] == 128.0 and t["pos"][0][1] == 128.0
+    A, B = (100.1 / 99.9), -(2 * 100 * 0.1) / 99.9
+    zn = (A * 0.9 + B) / 0.9
+    assert abs(t["pos"][0][2] - (zn * 49.95 + 50.05)) < 1e-3
+    assert 0.1 <= t["pos"][0][2] <= 100.0
+    assert tuple(t["uv"][0]) == (0.25, 0.75)
+    assert np.allclose(t["nrm"][0], (0, 0, 1))  # identity model: (M^-1)^T n with w=1, divided by w=1
+
+
+# ---------------------------------------------------------------------------------------------- bbox / cull
+def test_bbox_truncates_toward_zero_then_clamps(orc):
+    # x in [-3.7, 5.9] → trunc → [-3, 5] → clamp [0,5]; rows [2.2, 9.9] → [2, 9]; all columns < 8 wide-chunk → S class
+    t = tri((-3.7, 2.2), (5.9, 2.2), (1.0, 9.9))
+    rc, _, st = orc.draw(frame(t, eye=(0, 0, -1)))
+    assert rc == 0 and st["pixel_tests"] == 6 * 8 and st["n_culled"] == 0
+
+
+def test_offscreen_triangle_collapses_to_an_edge_column(orc):
+    t = tri((-50, 10), (-10, 10), (-30, 40))  # entirely left of the screen: bbox clamps to column 0
+    rc, pl, st = orc.draw(frame(t, eye=(0, 0, -1)))
+    assert st["pixel_tests"] == 1 * 31 and st["fragments"] == 0 and not np.isfinite(pl[0]).any()
+
+
+def test_backface_uses_eye_position(orc):
+    t = tri((10, 10), (50, 10), (30, 50))  # cross((40,0,0),(20,40,0)) = +z
+    assert orc.draw(frame(t, eye=(0, 0, 1)))[2]["n_culled"] == 1   # dot(n, eye) = +1 > 0 → culled
+    assert orc.draw(frame(t, eye=(0, 0, -1)))[2]["n_culled"] == 0
+    assert orc.draw(frame(t, eye=(0, 0, 0)))[2]["n_culled"] == 0   # dot == 0 is NOT > 0
+
+
+def test_nonfinite_vertex_is_dropped(orc):
+    t = tri((10, 10), (50, 10), (30, 50))
+    t["pos"][0][1][0] = np.nan
+    rc, pl, st = orc.draw(frame(t, eye=(0, 0, -1)))
+    assert rc == 0 and st["n_culled"] == 1 and not np.isfinite(pl[0]).any()
+
+
+# ---------------------------------------------------------------------------------------------- coverage
+def ccw(a, b, c, **kw):  # helper: a winding that survives the cull for eye=(0,0,1)
+    return tri(a, c, b, **kw)
+
+
+def test_pixels_on_an_edge_are_not_covered_in_either_class(orc):
+    # V class: legs of 32 → the area term is -1024, its reciprocal and every barycentric are exact in binary32, so the
+    # strict compares (0 < a,b,c < 1) exclude exactly the on-edge pixels.  bbox x 10..42 = 33 columns → V for x < 42.
+    t = ccw((10, 10), (42, 10), (10, 42))
+    rc, pl, st = orc.draw(frame(t))
+    cov = np.isfinite(pl[0])
+    assert not cov[:, 10].any() and not cov[10, :].any()
+    assert cov[11, 11] and cov[11, 40] and not cov[11, 41]     # hypotenuse x + y = 52
+    assert cov[30, 21] and not cov[30, 22]
+    assert int(cov.sum()) == sum(max(0, 52 - y - 11) for y in range(11, 42))
+    # S class: bbox 6 columns wide → every column is scalar-tail; edge functions on integers are exact
+    t = ccw((10, 10), (15, 10), (10, 15))
+    rc, pl, st = orc.draw(frame(t))
+    ys, xs = np.nonzero(np.isfinite(pl[0]))
+    assert sorted(zip(xs.tolist(), ys.tolist())) == [(11, 11), (11, 12), (11, 13), (12, 11), (12, 12), (13, 11)]
+
+
+def test_sample_point_is_the_pixel_corner_not_the_centre(orc):
+    # hypotenuse x+y = 24.5: integer corners with x,y >= 11 and x+y <= 24 are inside; the pixel (10,10), whose CENTRE
+    # (10.5,10.5) is inside, is not: the +0.5 of src/Rasterizer.cpp:465 is lost in the size_t parameter
+    t = ccw((10.25, 10.25), (14.25, 10.25), (10.25, 14.25))
+    rc, pl, st = orc.draw(frame(t))
+    ys, xs = np.nonzero(np.isfinite(pl[0]))
+    assert sorted(zip(xs.tolist(), ys.tolist())) == [(11, 11), (11, 12), (11, 13), (12, 11), (12, 12), (13, 11)]
+
+
+def test_v_columns_vs_scalar_tail_split(orc):
+    # bbox x 8..28 = 21 columns → V for x in [8,24), S for x in [24,28]
+    t = ccw((8, 8), (28.5, 8), (8, 28.5))
+    rc, pl, _ = orc.draw(frame(t))
+    c0 = pl[1]
+    assert c0[9, 12] == 127.5            # V class: float colour clamp01((0+1)*0.5)*255
+    assert c0[9, 25] == 127.0            # S class: normalizedToRGB truncates to an unsigned integer
+    assert pl[3][9, 12] == 0.0 and pl[3][9, 25] == 0.0
+
+
+def test_unified_flag_makes_every_column_v(orc):
+    t = ccw((8, 8), (28.5, 8), (8, 28.5))
+    rc, pl, _ = orc.draw(frame(t, flags=abi.FUSED_CLEAR | abi.UNIFIED))
+    assert pl[1][9, 25] == 127.5
+
+
+# ---------------------------------------------------------------------------------------------- z-test
+def test_z_tie_first_wins_in_v_columns_last_wins_in_scalar_tail(orc):
+    a = ccw((8, 8), (28.5, 8), (8, 28.5))
+    b = a.copy()
+    a["nrm"][0] = [[0, 0, -1]] * 3   # colour (127.5,127.5,0)
+    b["nrm"][0] = [[0, 0, 1]] * 3    # colour (127.5,127.5,255)
+    rc, pl, st = orc.draw(frame(np.concatenate([a, b])))
+    assert pl[3][9, 12] == 0.0       # V: z < zbuf is strict → the FIRST triangle keeps the pixel
+    assert pl[3][9, 25] == 255.0     # S: !(z > zbuf) → the LAST triangle overwrites
+    assert st["shaded"] > st["visible"]
+
+
+def test_nearer_triangle_wins_regardless_of_order(orc):
+    near = ccw((8, 8), (28.5, 8), (8, 28.5))
+    far = near.copy()
+    near["pos"][0][:, 2] = 40.0
+    far["pos"][0][:, 2] = 60.0
+    near["nrm"][0] = [[0, 0, 1]] * 3
+    for order in ([near, far], [far, near]):
+        rc, pl, _ = orc.draw(frame(np.concatenate(order)))
+        assert pl[0][9, 12] == 40.0 and pl[0][9, 25] == 40.0 and pl[3][9, 12] == 255.0
+
+
+def test_draw_never_clears_without_the_flag(orc):
+    t = ccw((8, 8), (28.5, 8), (8, 28.5))
+    z, c0, c1, c2 = orc.new_planes(64, 64)
+    z[:] = 45.0
+    c2[:] = 7.0
+    rc, pl, _ = orc.draw(frame(t, flags=0), (z, c0, c1, c2))   # z=50 is behind 45 → nothing drawn
+    assert (pl[0] == 45.0).all() and (pl[3] == 7.0).all()
+    z[:] = 55.0
+    rc, pl, _ = orc.draw(frame(t, flags=0), (z, c0, c1, c2))
+    assert pl[0][9, 12] == 50.0 and pl[0][40, 40] == 55.0 and pl[3][40, 40] == 7.0
+
+
+# ---------------------------------------------------------------------------------------------- texture / shading
+def test_texture_fetch_semantics(orc):
+    tex = np.zeros((4, 4, 3), np.uint8)
+    tex[:, :, 0] = np.arange(16).reshape(4, 4) * 10        # "blue" channel carries the texel id
+    tex[:, :, 1] = 255
+    orc.texture_set(5, tex)
+    lights = [((20, 20, 0), (0, 0, 0))]                     # zero intensity → colour = 0, only exercise the fetch path
+    t = ccw((8, 8), (28.5, 8), (8, 28.5), )
+    t["uv"][0] = [[1.0, 1.0]] * 3
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_TEXTURE, tex=5, lights=lights))
+    assert rc == 0
+    # with I=0 everything is 0; use ka*I path: give intensity via a second run
+    lights = [((20, 20, 0), (1e4, 1e4, 1e4))]
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_TEXTURE, tex=5, lights=lights))
+    # V class: u*texW clamped to texW-1 = 3 → texel (3,3) = id 15 → blue = 150/255 → saturates to 255 under I=1e4
+    assert pl[1][9, 12] == 255.0 and pl[2][9, 12] == 255.0 and pl[3][9, 12] == 0.0   # red channel of tex is 0
+    # S class: u == 1.0 → index == size → BLACK (src/TextureLoader.cpp:25-27)
+    assert pl[1][9, 25] == 0.0 and pl[2][9, 25] == 0.0 and pl[3][9, 25] == 0.0
+
+
+def test_missing_texture_is_an_error(orc):
+    t = ccw((8, 8), (28.5, 8), (8, 28.5))
+    rc, _, _ = orc.draw(frame(t, shader=abi.SHADER_TEXTURE, tex=63))
+    assert rc == abi.SRZ_E_TEXTURE
+
+
+def test_phong_known_value_v_class(orc):
+    """One light straight 'above' the pixel in screen space: closed-form Blinn-Phong of the reference's mixed-space model."""
+    t = ccw((8, 8), (28.5, 8), (8, 28.5), z=50.0)
+    t["nrm"][0] = [[0, 0, 1]] * 3
+    L = ((12.0, 9.0, 60.0), (10.0, 20.0, 30.0))
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_PHONG, lights=[L], eye=(0, 0, 1)))
+    y, z = 9.0, 50.0
+    # pixel (12,9): light_dir = (0,0,10) → att = 1/sqrt(0) = inf; the specular term is inf*0 = NaN and
+    # _mm256_max_ps(NaN, 0) = 0 (second operand) → the reference stores 0 there
+    assert pl[1][9, 12] == 0.0
+    x = 14.0   # pixel (14,9): light_dir = (-2,0,10), att = 1/2
+    l = np.array([12.0 - x, 0.0, 10.0])
+    att = 1.0 / np.hypot(l[0], l[1])
+    n = np.array([0, 0, 1.0])
+    cosA = max(0.0, (l / np.linalg.norm(l)) @ n)
+    h = l + (np.array([0, 0, 1.0]) - np.array([x, y, z]))
+    cosT = max(0.0, (h / np.linalg.norm(h)) @ n) ** 150
+    for ch, I in enumerate((10.0, 20.0, 30.0)):
+        c = 1.0 * (0.005 * I + (I * att * 1.0) * cosA + (I * att * 0.7937) * cosT)
+        expect = min(max(c, 0.0), 1.0) * 255.0
+        assert abs(pl[1 + ch][9, 14] - expect) < 1e-2
+
+
+def test_bump_and_displacement_are_white_in_v_columns(orc):
+    tex = np.full((4, 4, 3), 128, np.uint8)
+    orc.texture_set(6, tex)
+    t = ccw((8, 8), (28.5, 8), (8, 28.5))
+    for sh in (abi.SHADER_BUMP, abi.SHADER_DISPLACEMENT):
+        rc, pl, _ = orc.draw(frame(t, shader=sh, tex=6, lights=[((0, 0, 0), (1, 1, 1))]))
+        assert rc == 0 and pl[1][9, 12] == 255.0 and pl[2][9, 12] == 255.0 and pl[3][9, 12] == 255.0   # SIMD stubs
+
+
+# ---------------------------------------------------------------------------------------------- draw() contract
+def test_primitive_validation(orc):
+    t = ccw((8, 8), (28.5, 8), (8, 28.5))
+    assert orc.draw(frame(t), primitive=abi.PRIMITIVE_LINES)[0] == 0          # LINES draws filled triangles
+    assert orc.draw(frame(t), primitive=7)[0] == abi.SRZ_E_PRIMITIVE
+
+
+def test_resolve8_rounds_half_to_even_and_saturates(orc):
+    c = np.array([[0.5, 1.5, 2.5, 254.5, 255.5, 300.0, -3.0, np.nan]], F32)
+    out = orc.resolve8((None, c, c, c))
+    assert out[0, :, 0].tolist() == [0, 2, 2, 254, 255, 255, 0, 0]
+
+
+def test_config1_plumbing(orc):
+    import scenes
+    rc, pl, st = orc.draw(scenes.config1())
+    assert rc == 0 and st["n_tris"] == 3 and st["n_culled"] == 0
+    assert (pl[1][100, 128], pl[2][100, 128], pl[3][100, 128]) == (127.5, 127.5, 0.0)
+    assert pl[0][100, 128] == 50.0 and pl[0][150, 150] == 40.0   # the z=40 triangle wins where it overlaps
+    assert st["fragments"] > st["shaded"] >= st["visible"] > 0
+
+
+def test_omp_and_row_band_draws_equal_the_serial_draw(orc):
+    import scenes
+    f = scenes.config2(3, size=256)
+    rc, ref, _ = orc.draw(f)
+    pl = orc.new_planes(256, 256)
+    rc, n = orc.draw_omp(f, pl, band=8)
+    assert rc == 0 and n >= 1
+    for a, b in zip(pl, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
