@@ -25,6 +25,9 @@
 // and rounded once.  The z-buffer is therefore expected to be bit-identical to the oracle's.
 #include "srz_device.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace srz {
@@ -207,13 +210,19 @@ __global__ __launch_bounds__(256) void k_bands(RenderArgs a, RasterRec *band_rec
     }
     cursor += n;
   };
+  u32x2 nxt = {1u, 0u}, nxt2 = {1u, 0u}; // two chunks of bbox records in flight (empty box: sx=1 > ex=0)
+  if ((uint32_t)lane < n_tris) nxt = bbox[lane];
+  if ((uint32_t)lane + 64 < n_tris) nxt2 = bbox[lane + 64];
   for (uint32_t base = 0; base < n_tris; base += 64) {
     const uint32_t t = base + lane;
+    const u32x2 r = nxt;
+    nxt = nxt2;
+    nxt2 = u32x2{1u, 0u};
+    if (t + 128 < n_tris) nxt2 = bbox[t + 128];
     bool hit = false;
-    if (t < n_tris) {
-      const u32x2 r = bbox[t];
+    {
       const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
-      hit = sx <= ex && sy <= y1 && ey >= y0;
+      hit = t < n_tris && sx <= ex && sy <= y1 && ey >= y0;
     }
     const unsigned long long m = __ballot(hit);
     if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = t;
@@ -387,54 +396,65 @@ __device__ __forceinline__ void s_shade(const FrameK &K, const ShadeDesc &sd, fl
   r2 = (q2 == q2) ? (float)(uint32_t)q2 : 0.0f;
 }
 
+// bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
+constexpr uint32_t S_CLASS_BIT = 0x80000000u;
+
 // Everything the shader needs about the owner triangle of one pixel, fetched in ONE round trip (7 independent loads)
 struct TriFetch {
   f32x4 q0, q1, q2, q3, q4, q5;
-  u32x2 bb;
   uint32_t batch;
 };
-__device__ __forceinline__ void fetch_tri(const SRZ_CAS srz_tri *tris, const SRZ_CAS u32x2 *bbox,
-                                          const SRZ_CAS uint16_t *tri_batch, uint32_t idx, TriFetch &f) {
+__device__ __forceinline__ void fetch_tri(const SRZ_CAS srz_tri *tris, const SRZ_CAS uint16_t *tri_batch, uint32_t idx,
+                                          TriFetch &f) {
   const SRZ_CAS f32x4 *tp = reinterpret_cast<const SRZ_CAS f32x4 *>(tris + idx);
   f.q0 = tp[0], f.q1 = tp[1], f.q2 = tp[2], f.q3 = tp[3], f.q4 = tp[4], f.q5 = tp[5];
-  f.bb = bbox[idx];
   f.batch = tri_batch[idx];
 }
 
-// Shade pixel (x,y) of depth z with its final owner `f`.
-__device__ __forceinline__ void shade_pixel(const FrameK &K, const ShadeDesc &sd, uint32_t flags, const TriFetch &f, int x,
-                                            int y, float z, float &r0, float &r1, float &r2) {
-  // pos: q0.xyz q0.w q1.xy q1.zw q2.x | nrm: q2.yzw q3.xyz q3.w q4.xy | uv: q4.zw q5.xy q5.zw
+struct TriAttr {
   TriXY t;
-  t.ax = f.q0.x, t.ay = f.q0.y, t.z0 = f.q0.z, t.bx = f.q0.w, t.by = f.q1.x, t.z1 = f.q1.y, t.cx = f.q1.z, t.cy = f.q1.w,
-  t.z2 = f.q2.x;
-  tri_consts(t);
-  const float n0x = f.q2.y, n0y = f.q2.z, n0z = f.q2.w, n1x = f.q3.x, n1y = f.q3.y, n1z = f.q3.z, n2x = f.q3.w, n2y = f.q4.x,
-              n2z = f.q4.y;
-  const float u0 = f.q4.z, v0 = f.q4.w, u1 = f.q5.x, v1 = f.q5.y, u2 = f.q5.z, v2 = f.q5.w;
-  const int sx = (int16_t)(f.bb.x & 0xffff), ex = (int16_t)(f.bb.y & 0xffff);
-  const int vend = (flags & SRZ_UNIFIED) ? ex + 1 : sx + ((ex - sx + 1) & ~7);
+  float n0x, n0y, n0z, n1x, n1y, n1z, n2x, n2y, n2z, u0, v0, u1, v1, u2, v2;
+};
+__device__ __forceinline__ void unpack_tri(const TriFetch &f, TriAttr &a) {
+  // pos: q0.xyz q0.w q1.xy q1.zw q2.x | nrm: q2.yzw q3.xyz q3.w q4.xy | uv: q4.zw q5.xy q5.zw
+  a.t.ax = f.q0.x, a.t.ay = f.q0.y, a.t.z0 = f.q0.z, a.t.bx = f.q0.w, a.t.by = f.q1.x, a.t.z1 = f.q1.y, a.t.cx = f.q1.z,
+  a.t.cy = f.q1.w, a.t.z2 = f.q2.x;
+  tri_consts(a.t);
+  a.n0x = f.q2.y, a.n0y = f.q2.z, a.n0z = f.q2.w, a.n1x = f.q3.x, a.n1y = f.q3.y, a.n1z = f.q3.z, a.n2x = f.q3.w, a.n2y = f.q4.x,
+  a.n2z = f.q4.y;
+  a.u0 = f.q4.z, a.v0 = f.q4.w, a.u1 = f.q5.x, a.v1 = f.q5.y, a.u2 = f.q5.z, a.v2 = f.q5.w;
+}
+// Shade pixel (x,y) of depth z, owner `f`, 8-wide ("V") semantics (src/Rasterizer.cpp:380-389)
+__device__ __forceinline__ void shade_pixel_v(const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
+                                              float &r0, float &r1, float &r2) {
+  TriAttr a;
+  unpack_tri(f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
-  if (x < vend) {
-    cover_v(t, fx, fy, alpha, beta, gamma, zz);
-    float nx = fmaf_(alpha, n0x, fmaf_(beta, n1x, gamma * n2x));
-    float ny = fmaf_(alpha, n0y, fmaf_(beta, n1y, gamma * n2y));
-    float nz = fmaf_(alpha, n0z, fmaf_(beta, n1z, gamma * n2z));
-    v_normalized(nx, ny, nz);
-    float u = fmaf_(alpha, u0, fmaf_(beta, u1, gamma * u2));
-    float v = fmaf_(alpha, v0, fmaf_(beta, v1, gamma * v2));
-    v_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
-  } else {
-    cover_s(t, fx, fy, alpha, beta, gamma, zz);
-    float nx = alpha * n0x + beta * n1x + gamma * n2x;
-    float ny = alpha * n0y + beta * n1y + gamma * n2y;
-    float nz = alpha * n0z + beta * n1z + gamma * n2z;
-    normalize3(nx, ny, nz);
-    float u = alpha * u0 + beta * u1 + gamma * u2;
-    float v = alpha * v0 + beta * v1 + gamma * v2;
-    s_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
-  }
+  cover_v(a.t, fx, fy, alpha, beta, gamma, zz);
+  float nx = fmaf_(alpha, a.n0x, fmaf_(beta, a.n1x, gamma * a.n2x));
+  float ny = fmaf_(alpha, a.n0y, fmaf_(beta, a.n1y, gamma * a.n2y));
+  float nz = fmaf_(alpha, a.n0z, fmaf_(beta, a.n1z, gamma * a.n2z));
+  v_normalized(nx, ny, nz);
+  float u = fmaf_(alpha, a.u0, fmaf_(beta, a.u1, gamma * a.u2));
+  float v = fmaf_(alpha, a.v0, fmaf_(beta, a.v1, gamma * a.v2));
+  v_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+}
+// scalar-tail ("S") semantics (src/Rasterizer.cpp:470-492)
+__device__ __forceinline__ void shade_pixel_s(const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
+                                              float &r0, float &r1, float &r2) {
+  TriAttr a;
+  unpack_tri(f, a);
+  const float fx = (float)x, fy = (float)y;
+  float alpha, beta, gamma, zz;
+  cover_s(a.t, fx, fy, alpha, beta, gamma, zz);
+  float nx = alpha * a.n0x + beta * a.n1x + gamma * a.n2x;
+  float ny = alpha * a.n0y + beta * a.n1y + gamma * a.n2y;
+  float nz = alpha * a.n0z + beta * a.n1z + gamma * a.n2z;
+  normalize3(nx, ny, nz);
+  float u = alpha * a.u0 + beta * a.u1 + gamma * a.u2;
+  float v = alpha * a.v0 + beta * a.v1 + gamma * a.v2;
+  s_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
 }
 
 // ================================================================================================================
@@ -452,9 +472,9 @@ __device__ __forceinline__ void store_nt(float *p, const float4 &v) {
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_z[WAVES_PER_WG][TILE * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_id[WAVES_PER_WG][TILE * LDS_STRIDE];
+__global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_z[RASTER_WAVES][TILE * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_id[RASTER_WAVES][TILE * LDS_STRIDE];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: everything derived stays in SGPRs
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
   const int W = fd->width, H = fd->height;
   const uint32_t n_tris = fd->n_tris;
   const uint32_t flags = fd->flags | a.flags_or;
-  const int tx0 = ((int)blockIdx.x * WAVES_PER_WG + wave) * TILE;
+  const int tx0 = ((int)blockIdx.x * RASTER_WAVES + wave) * TILE;
   if (tx0 >= W) return; // whole wave leaves; no workgroup barrier is used in this kernel
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int ty0 = band * BAND;
@@ -560,7 +580,7 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
           pass = pass && act;
           if (pass) {
             zl[li] = z;
-            il[li] = idx;
+            il[li] = idx | ((x >= vend) ? S_CLASS_BIT : 0u); // owner + which of the two semantics produced it
           }
           any_owner |= pass;
           if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
@@ -576,7 +596,7 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
   //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
   //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
   const bool vec_ok = (W & 3) == 0;
-  if (tile_has_owner || fused) {
+  if ((tile_has_owner || fused) && !(flags & 0x400u)) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int it = 0; it < 4; ++it) {
       const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
@@ -636,14 +656,23 @@ __global__ __launch_bounds__(256) void k_raster(RenderArgs a) {
 }
 
 // ================================================================================================================
-// k_shade — VISIBILITY-FIRST SHADING: one workgroup per owned tile (persistent grid over the worklist)
+// k_shade — VISIBILITY-FIRST SHADING: one workgroup per owned tile (persistent grid over the worklist).
+// The tile's owned pixels are first COMPACTED by semantics class into two dense LDS lists (V from the front, S from
+// the back), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
+// colours go to LDS planes and leave as coalesced 16-byte stores.
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
+  __shared__ __attribute__((aligned(16))) float s_zv[TILE * TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
+  __shared__ uint16_t s_list[TILE * TILE];
+  __shared__ uint32_t s_cnt[2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t n_work = *as_const(a.work_count);
-  unsigned long long n_vis = 0, n_vis_tex = 0, n_calls = 0;
+  unsigned long long n_vis = 0, n_vis_tex = 0;
   for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
     const uint32_t e = as_const(a.worklist)[w];
     const uint32_t tx = e % a.tiles_x, rest = e / a.tiles_x;
@@ -659,7 +688,6 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
     K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
     K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
     K.lights = as_const(a.lights) + fd->light_off;
-    const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox)) + tri_off;
     const SRZ_CAS srz_tri *tris = as_const(a.tris) + tri_off;
     const SRZ_CAS uint16_t *tri_batch = as_const(a.tri_batch) + tri_off;
     const SRZ_CAS ShadeDescG *sdesc = as_const(a.sdesc) + batch_off;
@@ -672,14 +700,16 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
     float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
     const uint32_t *vis0 = a.vis + ((size_t)f * a.local_rows + row0) * (size_t)W;
 
+    // ---- 1. load this thread's 4 pixels (z, owner id, old colour unless fused) into LDS, classify, compact ------
     const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int y = ty0 + ly, x4 = tx0 + lx4;
-    if (y > ty1 || x4 > tx1) continue;
-    const bool full = ((W & 3) == 0) && x4 + 3 <= tx1;
+    const bool in_tile = y <= ty1 && x4 <= tx1;
+    const bool full = in_tile && ((W & 3) == 0) && x4 + 3 <= tx1;
     float *gz = out0 + (size_t)ly * W + x4;
     const uint32_t *gv = vis0 + (size_t)ly * W + x4;
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), C0 = z4, C1 = z4, C2 = z4;
     uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
+    if (tid == 0) s_cnt[0] = 0, s_cnt[1] = 0;
     if (full) {
       z4 = *reinterpret_cast<const float4 *>(gz);
       id4 = *reinterpret_cast<const uint4 *>(gv);
@@ -688,7 +718,7 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
         C1 = *reinterpret_cast<const float4 *>(gz + 2 * plane);
         C2 = *reinterpret_cast<const float4 *>(gz + 3 * plane);
       }
-    } else {
+    } else if (in_tile) {
 #define SRZ_LD(K_, M)                                                                                                  \
   if (x4 + K_ <= tx1) {                                                                                                \
     z4.M = gz[K_], id4.M = gv[K_];                                                                                     \
@@ -697,53 +727,87 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
       SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
 #undef SRZ_LD
     }
-    if (!(flags & 0x200u)) {
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t id = k == 0 ? id4.x : k == 1 ? id4.y : k == 2 ? id4.z : id4.w;
-        const float z = k == 0 ? z4.x : k == 1 ? z4.y : k == 2 ? z4.z : z4.w;
-        if (id != NO_TRI) {
-          TriFetch tf;
-          fetch_tri(tris, bbox, tri_batch, id, tf);
-          const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-          ShadeDesc sd;
-          sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-          float r0, r1, r2;
-          shade_pixel(K, sd, flags, tf, x4 + k, y, z, r0, r1, r2);
-          if (k == 0) C0.x = r0, C1.x = r1, C2.x = r2;
-          if (k == 1) C0.y = r0, C1.y = r1, C2.y = r2;
-          if (k == 2) C0.z = r0, C1.z = r1, C2.z = r2;
-          if (k == 3) C0.w = r0, C1.w = r1, C2.w = r2;
-          if (STATS) {
-            const bool textured =
-                sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP;
-            n_vis++, n_vis_tex += textured ? 1 : 0;
-          }
-        }
-        if (STATS && __ballot(id != NO_TRI) != 0 && lane == __builtin_ctzll(__ballot(1))) n_calls++;
+    if (flags & 0x200u) id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
+    const int p0 = ly * TILE + lx4;
+    *reinterpret_cast<float4 *>(&s_zv[p0]) = z4;
+    *reinterpret_cast<uint4 *>(&s_ids[p0]) = id4;
+    *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
+    *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
+    *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
+    __syncthreads(); // s_cnt zeroed
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t id = k == 0 ? id4.x : k == 1 ? id4.y : k == 2 ? id4.z : id4.w;
+      const bool own = id != NO_TRI, isS = own && (id & S_CLASS_BIT) != 0, isV = own && !isS;
+      const unsigned long long mv = __ballot(isV), ms = __ballot(isS);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      uint32_t bv = 0, bs = 0;
+      if (lane == 0) {
+        if (mv) bv = atomicAdd(&s_cnt[0], (uint32_t)__popcll(mv));
+        if (ms) bs = atomicAdd(&s_cnt[1], (uint32_t)__popcll(ms));
       }
+      bv = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv), bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
+      if (isV) s_list[bv + __popcll(mv & lt)] = (uint16_t)(p0 + k);
+      if (isS) s_list[TILE * TILE - 1 - (bs + __popcll(ms & lt))] = (uint16_t)(p0 + k);
     }
+    __syncthreads();
+    const uint32_t nV = s_cnt[0], nS = s_cnt[1];
+
+    // ---- 2. dense V pass, dense S pass ------------------------------------------------------------------------------
+    for (uint32_t i = tid; i < nV; i += 256) {
+      const uint32_t p = s_list[i];
+      const uint32_t id = s_ids[p];
+      TriFetch tf;
+      fetch_tri(tris, tri_batch, id, tf);
+      const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+      ShadeDesc sd;
+      sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+      float r0, r1, r2;
+      shade_pixel_v(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
+      s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
+      if (STATS)
+        n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
+    }
+    for (uint32_t i = tid; i < nS; i += 256) {
+      const uint32_t p = s_list[TILE * TILE - 1 - i];
+      const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
+      TriFetch tf;
+      fetch_tri(tris, tri_batch, id, tf);
+      const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+      ShadeDesc sd;
+      sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+      float r0, r1, r2;
+      shade_pixel_s(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
+      s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
+      if (STATS)
+        n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
+    }
+    __syncthreads();
+
+    // ---- 3. coalesced write-out of the three colour planes ----------------------------------------------------------
+    C0 = *reinterpret_cast<const float4 *>(&s_c[0][p0]);
+    C1 = *reinterpret_cast<const float4 *>(&s_c[1][p0]);
+    C2 = *reinterpret_cast<const float4 *>(&s_c[2][p0]);
     if (full) {
       store_nt(gz + plane, C0);
       store_nt(gz + 2 * plane, C1);
       store_nt(gz + 3 * plane, C2);
-    } else {
+    } else if (in_tile) {
 #define SRZ_ST(K_, M)                                                                                                  \
   if (x4 + K_ <= tx1) gz[plane + K_] = C0.M, gz[2 * plane + K_] = C1.M, gz[3 * plane + K_] = C2.M;
       SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
     }
+    __syncthreads(); // LDS is reused by the next tile of this persistent workgroup
   }
   if (STATS) {
     for (int o = 32; o > 0; o >>= 1) {
       n_vis += __shfl_down(n_vis, o);
       n_vis_tex += __shfl_down(n_vis_tex, o);
-      n_calls += __shfl_down(n_calls, o);
     }
     if (lane == 0) {
       if (n_vis) atomicAdd(&a.stats[ST_VISIBLE], n_vis);
       if (n_vis_tex) atomicAdd(&a.stats[ST_VISIBLE_TEX], n_vis_tex);
-      if (n_calls) atomicAdd(&a.stats[ST_DBG_SHADE_CALLS], n_calls);
     }
   }
 }
@@ -787,11 +851,19 @@ void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream
 
 void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s) {
   if (n_frames <= 0 || max_local_bands == 0) return;
-  dim3 grid((width + TILE * WAVES_PER_WG - 1) / (TILE * WAVES_PER_WG), max_local_bands, n_frames);
+  static bool once = false;
+  if (!once && getenv("SRZ_DEBUG")) {
+    once = true;
+    int nb = 0, ns = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raster<false>, 64 * RASTER_WAVES, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, k_shade<false>, 256, 0);
+    fprintf(stderr, "[srz] occupancy: k_raster %d WGs/CU (x%d waves), k_shade %d WGs/CU\n", nb, RASTER_WAVES, ns);
+  }
+  dim3 grid((width + TILE * RASTER_WAVES - 1) / (TILE * RASTER_WAVES), max_local_bands, n_frames);
   if (stats)
-    hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_raster<true>, grid, dim3(64 * RASTER_WAVES), 0, s, a);
   else
-    hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_raster<false>, grid, dim3(64 * RASTER_WAVES), 0, s, a);
 }
 
 void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s) {
