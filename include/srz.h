@@ -160,6 +160,9 @@ int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
 int srz_sync(srz_ctx *ctx);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
+/* diagnostic only: arm!=0 allocates a per-tile timeline filled by the next srz_frameset_stats; arm==0 copies it out
+ * (4 x u64 per tile: start, end in 100 MHz ticks, HW_ID, 8x8 blocks) */
+int srz_debug_timeline(srz_ctx *ctx, uint64_t *out, size_t n_tiles, int arm);
 
 #ifdef __cplusplus
 }

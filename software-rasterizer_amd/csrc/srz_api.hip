@@ -34,6 +34,8 @@ struct srz_ctx {
   uint64_t tex_version = 1;
   int acc_launches = 0;
   unsigned long long dbg[ST_COUNT] = {};
+  unsigned long long *d_timeline = nullptr; // diagnostic buffer (srz_debug_timeline)
+  size_t timeline_cap = 0;
 };
 
 struct srz_frameset {
@@ -117,6 +119,7 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.work_count = fs->d_work_count;
   a.tiles_x = fs->tiles_x;
   a.n_local_bands = fs->n_local_bands;
+  a.n_frames = (uint32_t)fs->n_frames;
   a.band_count = fs->d_band_count;
   a.out = d_out;
   a.local_rows = fs->local_rows;
@@ -125,6 +128,7 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.shard_world = fs->shard_world;
   a.flags_or = flags_or;
   a.stats = ctx->d_stats;
+  a.timeline = nullptr;
   return a;
 }
 
@@ -179,6 +183,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     fs->sdesc_version = ctx->tex_version;
   }
   RenderArgs a = make_args(ctx, fs, d_out, flags_or);
+  a.timeline = ctx->d_timeline; // null unless armed by srz_debug_timeline
   EventPair ep{};
   bool timed = ctx->timing && !stats && ctx->ev_used.size() < 65536;
   if (timed) {
@@ -490,6 +495,23 @@ int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches) {
     if (ms4) ms4[i] = ctx->acc_launches ? ctx->acc_ms[i] / ctx->acc_launches : 0.0;
   if (launches) *launches = ctx->acc_launches;
   if (reset) ctx->acc_ms[0] = ctx->acc_ms[1] = ctx->acc_ms[2] = ctx->acc_ms[3] = 0.0, ctx->acc_launches = 0;
+  return SRZ_OK;
+}
+
+/* diagnostic: per-tile {start,end (100 MHz wall clock), HW_ID, blocks} of the next stats run; cap = tiles */
+int srz_debug_timeline(srz_ctx *ctx, uint64_t *out, size_t n_tiles, int arm) {
+  if (!ctx) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (arm) {
+    (void)hipFree(ctx->d_timeline);
+    ctx->d_timeline = nullptr;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_timeline, n_tiles * 32));
+    HIP_TRY(ctx, hipMemset(ctx->d_timeline, 0, n_tiles * 32));
+    ctx->timeline_cap = n_tiles;
+    return SRZ_OK;
+  }
+  if (!ctx->d_timeline || !out || n_tiles > ctx->timeline_cap) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_timeline, n_tiles * 32, hipMemcpyDeviceToHost));
   return SRZ_OK;
 }
 

@@ -82,13 +82,14 @@ struct RenderArgs {
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
   uint32_t *worklist;            // tiles that need shading: (frame*n_local_bands + lb)*tiles_x + tx
   uint32_t *work_count;
-  uint32_t tiles_x, n_local_bands;
+  uint32_t tiles_x, n_local_bands, n_frames;
   float *out;             // [frame][4][local_rows][width]
   uint64_t frame_stride;  // floats per frame in out = 4*local_rows*width
   uint32_t local_rows;    // rows per plane in out
   int32_t shard_rank, shard_world;
   uint32_t flags_or;      // OR-ed into every frame's flags (SRZ_FUSED_CLEAR / SRZ_UNIFIED)
   unsigned long long *stats;
+  unsigned long long *timeline; // diagnostic (STATS variant only): per tile {start, end (wall clock 100 MHz), hw_id, blocks}
 };
 
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);

@@ -477,14 +477,22 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_id[RASTER_WAVES][TILE * LDS_STRIDE];
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // scalar: everything derived stays in SGPRs
-  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.z;
-  const uint32_t lb = blockIdx.y;
-  if (lb >= fd->n_local_bands) return;
+  // XCD-aware tile assignment.  Workgroups are dealt round-robin to the 8 XCDs in launch order, and launch order is
+  // strict: one XCD whose slots are full of long tiles stalls the dispatch of everything behind it.  So workgroup i
+  // renders frame (i % 8) of its group of 8 frames: the 8 XCDs walk the SAME tile sequence in lockstep (balanced by
+  // construction), and all tiles of one frame — hence its band lists — live in ONE XCD's L2.
+  const uint32_t wg = blockIdx.x;
+  const uint32_t xcd = wg & 7u, j = wg >> 3;
+  const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
+  const uint32_t frame = (j / tiles_per_frame) * 8u + xcd, tile = j % tiles_per_frame;
+  if (frame >= a.n_frames) return;
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
+  const uint32_t lb = tile / a.tiles_x;
   const int W = fd->width, H = fd->height;
   const uint32_t n_tris = fd->n_tris;
   const uint32_t flags = fd->flags | a.flags_or;
-  const int tx0 = ((int)blockIdx.x * RASTER_WAVES + wave) * TILE;
+  const int wave = 0;
+  const int tx0 = (int)(tile % a.tiles_x) * TILE;
   if (tx0 >= W) return; // whole wave leaves; no workgroup barrier is used in this kernel
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int ty0 = band * BAND;
@@ -495,10 +503,12 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
 
   const size_t plane = (size_t)a.local_rows * (size_t)W;
   const size_t row0 = (size_t)lb * BAND;
-  float *out0 = a.out + (size_t)blockIdx.z * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
-  uint32_t *vis0 = a.vis + ((size_t)blockIdx.z * a.local_rows + row0) * (size_t)W;
+  float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
+  uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
 
   const unsigned long long tA = STATS ? __builtin_readcyclecounter() : 0;
+  const unsigned long long wallA = a.timeline ? wall_clock64() : 0;
+  uint32_t n_hit_tris = 0;
   // ---- phase A: tile init (fused clear → +inf, else load the in/out z plane) ---------------------------------
   for (int i = lane; i < TILE * TILE; i += 64) {
     int ly = i >> 5, lx = i & 31;
@@ -544,6 +554,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
     t.v_inv = t.s_area = 0.0f;
     if (hit) tri_consts(t);
     unsigned long long m = __ballot(hit);
+    n_hit_tris += (uint32_t)__popcll(m);
     while (m) {
       const int j = __builtin_ctzll(m);
       m &= m - 1;
@@ -634,7 +645,13 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   }
   if (tile_has_owner && lane == 0) {
     const uint32_t slot = atomicAdd(a.work_count, 1u);
-    a.worklist[slot] = ((uint32_t)blockIdx.z * a.n_local_bands + lb) * a.tiles_x + (uint32_t)(tx0 / TILE);
+    a.worklist[slot] = (frame * a.n_local_bands + lb) * a.tiles_x + (uint32_t)(tx0 / TILE);
+  }
+  if (a.timeline && lane == 0) { // diagnostic: per-tile residency (srz_debug_timeline)
+    unsigned hw = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long *tl = a.timeline + 4ull * ((size_t)frame * tiles_per_frame + tile);
+    tl[0] = wallA, tl[1] = wall_clock64(), tl[2] = hw, tl[3] = n_hit_tris;
   }
   if (STATS) {
     const unsigned long long tD = __builtin_readcyclecounter();
@@ -859,7 +876,8 @@ void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, 
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, k_shade<false>, 256, 0);
     fprintf(stderr, "[srz] occupancy: k_raster %d WGs/CU (x%d waves), k_shade %d WGs/CU\n", nb, RASTER_WAVES, ns);
   }
-  dim3 grid((width + TILE * RASTER_WAVES - 1) / (TILE * RASTER_WAVES), max_local_bands, n_frames);
+  const uint32_t groups = ((uint32_t)n_frames + 7u) / 8u;
+  dim3 grid(groups * 8u * a.n_local_bands * a.tiles_x);
   if (stats)
     hipLaunchKernelGGL(k_raster<true>, grid, dim3(64 * RASTER_WAVES), 0, s, a);
   else
