@@ -568,35 +568,91 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
       const int sx = (int16_t)(px & 0xffff), sy = (int16_t)(px >> 16), ex = (int16_t)(py & 0xffff), ey = (int16_t)(py >> 16);
       const int rx0 = max(sx, tx0), rx1 = min(ex, tx1), ry0 = max(sy, ty0), ry1 = min(ey, ty1);
       const int vend = (flags & SRZ_UNIFIED) ? ex + 1 : sx + ((ex - sx + 1) & ~7);
-      for (int yb = ry0; yb <= ry1; yb += 8) {
-        for (int xb = rx0; xb <= rx1; xb += 8) {
-          const int x = xb + (lane & 7), y = yb + (lane >> 3);
-          const bool act = x <= rx1 && y <= ry1;
-          const int li = (y - ty0) * LDS_STRIDE + (x - tx0);
-          const float fx = (float)x, fy = (float)y;
-          float al, be, ga, z = 0.0f;
-          bool inside = false, pass = false;
-          const bool anyV = xb < vend, anyS = min(xb + 7, rx1) >= vend; // wave-uniform
-          float zold = 0.0f;
-          if (act) zold = zl[li];
-          if (anyV && (!anyS || x < vend)) {
-            inside = cover_v(u, fx, fy, al, be, ga, z);
-            pass = inside && (z < zold); // strict (src/Rasterizer.cpp:334)
+      const int rh = ry1 - ry0 + 1;
+      // The triangle's columns split into the "V" part [rx0, xv1] and the scalar-tail "S" part [xs0, rx1] (<= 7 wide);
+      // each part is swept by its own loop with its own predicated body (no per-block class logic, no mixed blocks).
+      // The 64 lanes form a BW x BH pixel block whose shape (8x8, 16x4 or 4x16) is chosen per part to minimise the
+      // number of blocks (-16 % on the spot scene).
+      const int xv1 = min(rx1, vend - 1), xs0 = max(rx0, vend);
+#define SRZ_PICK_SHAPE(W_, LOG_BW)                                                                                     \
+  {                                                                                                                    \
+    const int n88 = ((W_ + 7) >> 3) * ((rh + 7) >> 3), n164 = ((W_ + 15) >> 4) * ((rh + 3) >> 2),                     \
+              n416 = ((W_ + 3) >> 2) * ((rh + 15) >> 4);                                                               \
+    LOG_BW = 3;                                                                                                        \
+    if (n164 < n88 && n164 <= n416) LOG_BW = 4;                                                                        \
+    if (n416 < n88 && n416 < n164) LOG_BW = 2;                                                                         \
+  }
+      if (xv1 >= rx0 && ry1 >= ry0) {
+        int lbw;
+        SRZ_PICK_SHAPE((xv1 - rx0 + 1), lbw)
+        const int bw = 1 << lbw, bh = 64 >> lbw;
+        const int lx = lane & (bw - 1), ly = lane >> lbw;
+        for (int yb = ry0; yb <= ry1; yb += bh) {
+          const int y = yb + ly;
+          const float fy = (float)y;
+          const float PBy = u.by - fy, PCy = u.cy - fy, PAy = u.ay - fy;
+          const bool rowok = y <= ry1;
+          const int lrow = (y - ty0) * LDS_STRIDE - tx0;
+          for (int xb = rx0; xb <= xv1; xb += bw) {
+            const int x = xb + lx;
+            const float fx = (float)x;
+            const float PBx = u.bx - fx, PCx = u.cx - fx, PAx = u.ax - fx;
+            const float aPBC = fmsubf(PBx, PCy, PCx * PBy), aPCA = fmsubf(PCx, PAy, PAx * PCy);
+            const float al = aPBC * u.v_inv, be = aPCA * u.v_inv, ga = 1.0f - (al + be);
+            const float z = fmaf_(al, u.z0, fmaf_(be, u.z1, ga * u.z2));
+            const int li = min(lrow + x, TILE * LDS_STRIDE - 1); // clamped: lanes outside the part read a valid word
+            const float zold = zl[li];
+            // 0<al<1 & 0<be<1 & 0<ga<1  <=>  al>0 & be>0 & ga>0 & ga<1 (al+be is rounded monotonically, so ga>0
+            // forces al,be <= al+be < 1); every compare is ordered, so NaNs reject exactly like _CMP_*_OQ
+            const bool inside = rowok & (x <= xv1) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
+            const bool pass = inside & (z < zold); // strict (src/Rasterizer.cpp:334)
+            if (pass) {
+              zl[li] = z;
+              il[li] = idx;
+            }
+            any_owner |= pass;
+            if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
           }
-          if (anyS && (!anyV || x >= vend)) {
-            inside = cover_s(u, fx, fy, al, be, ga, z);
-            pass = inside && !(z > zold); // <= passes, NaN passes (src/Rasterizer.cpp:475)
-          }
-          inside = inside && act;
-          pass = pass && act;
-          if (pass) {
-            zl[li] = z;
-            il[li] = idx | ((x >= vend) ? S_CLASS_BIT : 0u); // owner + which of the two semantics produced it
-          }
-          any_owner |= pass;
-          if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
         }
       }
+      if (rx1 >= xs0 && ry1 >= ry0) {
+        int lbw;
+        SRZ_PICK_SHAPE((rx1 - xs0 + 1), lbw)
+        const int bw = 1 << lbw, bh = 64 >> lbw;
+        const int lx = lane & (bw - 1), ly = lane >> lbw;
+        const float ABx = u.bx - u.ax, ABy = u.by - u.ay, BCx = u.cx - u.bx, BCy = u.cy - u.by, CAx = u.ax - u.cx,
+                    CAy = u.ay - u.cy;
+        for (int yb = ry0; yb <= ry1; yb += bh) {
+          const int y = yb + ly;
+          const float fy = (float)y;
+          const bool rowok = y <= ry1;
+          const int lrow = (y - ty0) * LDS_STRIDE - tx0;
+          for (int xb = xs0; xb <= rx1; xb += bw) {
+            const int x = xb + lx;
+            const float fx = (float)x;
+            // insideTriangle (src/Rasterizer.cpp:11-41)
+            const float APx = fx - u.ax, APy = fy - u.ay, BPx = fx - u.bx, BPy = fy - u.by, CPx = fx - u.cx, CPy = fy - u.cy;
+            const float e0 = ABx * APy - ABy * APx, e1 = BCx * BPy - BCy * BPx, e2 = CAx * CPy - CAy * CPx;
+            const bool in_tri = ((e0 > 0) & (e1 > 0) & (e2 > 0)) | ((e0 < 0) & (e1 < 0) & (e2 < 0));
+            // barycentric (scalar) + z (src/Rasterizer.cpp:43-70,473)
+            const float PAx = u.ax - fx, PAy = u.ay - fy, PBx = u.bx - fx, PBy = u.by - fy, PCx = u.cx - fx, PCy = u.cy - fy;
+            const float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
+            const float al = aPBC / u.s_area, be = aPCA / u.s_area, ga = 1.0f - al - be;
+            const float z = al * u.z0 + be * u.z1 + ga * u.z2;
+            const int li = min(lrow + x, TILE * LDS_STRIDE - 1);
+            const float zold = zl[li];
+            const bool inside = rowok & (x <= rx1) & in_tri;
+            const bool pass = inside & !(z > zold); // <= passes, NaN passes (src/Rasterizer.cpp:475)
+            if (pass) {
+              zl[li] = z;
+              il[li] = idx | S_CLASS_BIT;
+            }
+            any_owner |= pass;
+            if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
+          }
+        }
+      }
+#undef SRZ_PICK_SHAPE
     }
   }
   __builtin_amdgcn_wave_barrier();
