@@ -526,7 +526,6 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   const SRZ_CAS f32x4 *recs =
       reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.band_recs) + fd->list_off + (uint64_t)lb * n_tris);
   unsigned long long n_frag = 0, n_shaded = 0;
-  bool any_owner = false;
 
   // software pipeline: the next chunk's records are in flight while the current chunk is rasterised
   f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0, n2 = n0;
@@ -547,12 +546,33 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
     // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx
     // (by-value helper: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
     const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z), my = f2u(r2.w);
-    const int bsx = (int16_t)(bbx & 0xffff), bex = (int16_t)(bby & 0xffff);
+    const int bsx = (int16_t)(bbx & 0xffff), bsy = (int16_t)(bbx >> 16), bex = (int16_t)(bby & 0xffff), bey = (int16_t)(bby >> 16);
     const bool hit = valid && bex >= tx0 && bsx <= tx1;
     TriXY t;
     t.ax = r0.x, t.ay = r0.y, t.z0 = r0.z, t.bx = r0.w, t.by = r1.x, t.z1 = r1.y, t.cx = r1.z, t.cy = r1.w, t.z2 = r2.x;
     t.v_inv = t.s_area = 0.0f;
-    if (hit) tri_consts(t);
+    // Per-lane (= per-triangle) geometry of bbox ∩ tile in TILE-LOCAL coordinates, computed for the whole chunk in
+    // parallel and packed into one word so that the serial per-triangle loop only unpacks it:
+    //   [4:0] x0  [9:5] x1  [14:10] y0  [19:15] y1  [25:20] v = first scalar-tail column (V part = [x0,v-1], S = [v,x1])
+    //   [27:26] log2(block width) of the V sweep  [29:28] of the S sweep   (block = BW x 64/BW pixels: 8x8, 16x4, 4x16,
+    //   whichever needs the fewest blocks)
+    uint32_t geom = 0;
+    if (hit) {
+      tri_consts(t);
+      const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
+      const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
+      const int v = min(max(vend - tx0, x0), x1 + 1);
+      const int h = y1 - y0 + 1, wv = v - x0, ws = x1 + 1 - v;
+      auto pick = [h](int w) {
+        const int n88 = ((w + 7) >> 3) * ((h + 7) >> 3), n164 = ((w + 15) >> 4) * ((h + 3) >> 2), n416 = ((w + 3) >> 2) * ((h + 15) >> 4);
+        int l = 3;
+        if (n164 < n88 && n164 <= n416) l = 4;
+        if (n416 < n88 && n416 < n164) l = 2;
+        return l;
+      };
+      geom = (uint32_t)x0 | ((uint32_t)x1 << 5) | ((uint32_t)y0 << 10) | ((uint32_t)y1 << 15) | ((uint32_t)v << 20) |
+             ((uint32_t)(pick(wv) - 2) << 26) | ((uint32_t)(pick(ws) - 2) << 28);
+    }
     unsigned long long m = __ballot(hit);
     n_hit_tris += (uint32_t)__popcll(m);
     while (m) {
@@ -564,72 +584,50 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
       u.cy = rl_f(t.cy, j), u.z0 = rl_f(t.z0, j), u.z1 = rl_f(t.z1, j), u.z2 = rl_f(t.z2, j);
       u.v_inv = rl_f(t.v_inv, j), u.s_area = rl_f(t.s_area, j);
       const uint32_t idx = (uint32_t)rl_i((int)my, j);
-      const int px = rl_i((int)bbx, j), py = rl_i((int)bby, j);
-      const int sx = (int16_t)(px & 0xffff), sy = (int16_t)(px >> 16), ex = (int16_t)(py & 0xffff), ey = (int16_t)(py >> 16);
-      const int rx0 = max(sx, tx0), rx1 = min(ex, tx1), ry0 = max(sy, ty0), ry1 = min(ey, ty1);
-      const int vend = (flags & SRZ_UNIFIED) ? ex + 1 : sx + ((ex - sx + 1) & ~7);
-      const int rh = ry1 - ry0 + 1;
-      // The triangle's columns split into the "V" part [rx0, xv1] and the scalar-tail "S" part [xs0, rx1] (<= 7 wide);
-      // each part is swept by its own loop with its own predicated body (no per-block class logic, no mixed blocks).
-      // The 64 lanes form a BW x BH pixel block whose shape (8x8, 16x4 or 4x16) is chosen per part to minimise the
-      // number of blocks (-16 % on the spot scene).
-      const int xv1 = min(rx1, vend - 1), xs0 = max(rx0, vend);
-#define SRZ_PICK_SHAPE(W_, LOG_BW)                                                                                     \
-  {                                                                                                                    \
-    const int n88 = ((W_ + 7) >> 3) * ((rh + 7) >> 3), n164 = ((W_ + 15) >> 4) * ((rh + 3) >> 2),                     \
-              n416 = ((W_ + 3) >> 2) * ((rh + 15) >> 4);                                                               \
-    LOG_BW = 3;                                                                                                        \
-    if (n164 < n88 && n164 <= n416) LOG_BW = 4;                                                                        \
-    if (n416 < n88 && n416 < n164) LOG_BW = 2;                                                                         \
-  }
-      if (xv1 >= rx0 && ry1 >= ry0) {
-        int lbw;
-        SRZ_PICK_SHAPE((xv1 - rx0 + 1), lbw)
-        const int bw = 1 << lbw, bh = 64 >> lbw;
+      const uint32_t g = (uint32_t)rl_i((int)geom, j);
+      const int x0 = g & 31, x1 = (g >> 5) & 31, y0 = (g >> 10) & 31, y1 = (g >> 15) & 31, vx = (g >> 20) & 63;
+      if (y1 < y0) continue; // (cannot happen for a band hit; keeps the loops well-formed)
+      if (vx > x0) { // ---- "V" sweep over columns [x0, vx-1] -------------------------------------------------
+        const int lbw = (int)((g >> 26) & 3) + 2, bw = 1 << lbw, bh = 64 >> lbw;
         const int lx = lane & (bw - 1), ly = lane >> lbw;
-        for (int yb = ry0; yb <= ry1; yb += bh) {
-          const int y = yb + ly;
-          const float fy = (float)y;
+        for (int yb = y0; yb <= y1; yb += bh) {
+          const int yl = yb + ly;
+          const float fy = (float)(ty0 + yl);
           const float PBy = u.by - fy, PCy = u.cy - fy, PAy = u.ay - fy;
-          const bool rowok = y <= ry1;
-          const int lrow = (y - ty0) * LDS_STRIDE - tx0;
-          for (int xb = rx0; xb <= xv1; xb += bw) {
-            const int x = xb + lx;
-            const float fx = (float)x;
+          const bool rowok = yl <= y1;
+          for (int xb = x0; xb < vx; xb += bw) {
+            const int xl = xb + lx;
+            const float fx = (float)(tx0 + xl);
             const float PBx = u.bx - fx, PCx = u.cx - fx, PAx = u.ax - fx;
             const float aPBC = fmsubf(PBx, PCy, PCx * PBy), aPCA = fmsubf(PCx, PAy, PAx * PCy);
             const float al = aPBC * u.v_inv, be = aPCA * u.v_inv, ga = 1.0f - (al + be);
             const float z = fmaf_(al, u.z0, fmaf_(be, u.z1, ga * u.z2));
-            const int li = min(lrow + x, TILE * LDS_STRIDE - 1); // clamped: lanes outside the part read a valid word
+            const int li = min(yl * LDS_STRIDE + xl, TILE * LDS_STRIDE - 1); // clamped: idle lanes read a valid word
             const float zold = zl[li];
             // 0<al<1 & 0<be<1 & 0<ga<1  <=>  al>0 & be>0 & ga>0 & ga<1 (al+be is rounded monotonically, so ga>0
             // forces al,be <= al+be < 1); every compare is ordered, so NaNs reject exactly like _CMP_*_OQ
-            const bool inside = rowok & (x <= xv1) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
+            const bool inside = rowok & (xl < vx) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
             const bool pass = inside & (z < zold); // strict (src/Rasterizer.cpp:334)
             if (pass) {
               zl[li] = z;
               il[li] = idx;
             }
-            any_owner |= pass;
             if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
           }
         }
       }
-      if (rx1 >= xs0 && ry1 >= ry0) {
-        int lbw;
-        SRZ_PICK_SHAPE((rx1 - xs0 + 1), lbw)
-        const int bw = 1 << lbw, bh = 64 >> lbw;
+      if (vx <= x1) { // ---- scalar-tail "S" sweep over columns [vx, x1] (<= 7 wide) -----------------------------
+        const int lbw = (int)((g >> 28) & 3) + 2, bw = 1 << lbw, bh = 64 >> lbw;
         const int lx = lane & (bw - 1), ly = lane >> lbw;
         const float ABx = u.bx - u.ax, ABy = u.by - u.ay, BCx = u.cx - u.bx, BCy = u.cy - u.by, CAx = u.ax - u.cx,
                     CAy = u.ay - u.cy;
-        for (int yb = ry0; yb <= ry1; yb += bh) {
-          const int y = yb + ly;
-          const float fy = (float)y;
-          const bool rowok = y <= ry1;
-          const int lrow = (y - ty0) * LDS_STRIDE - tx0;
-          for (int xb = xs0; xb <= rx1; xb += bw) {
-            const int x = xb + lx;
-            const float fx = (float)x;
+        for (int yb = y0; yb <= y1; yb += bh) {
+          const int yl = yb + ly;
+          const float fy = (float)(ty0 + yl);
+          const bool rowok = yl <= y1;
+          for (int xb = vx; xb <= x1; xb += bw) {
+            const int xl = xb + lx;
+            const float fx = (float)(tx0 + xl);
             // insideTriangle (src/Rasterizer.cpp:11-41)
             const float APx = fx - u.ax, APy = fy - u.ay, BPx = fx - u.bx, BPy = fy - u.by, CPx = fx - u.cx, CPy = fy - u.cy;
             const float e0 = ABx * APy - ABy * APx, e1 = BCx * BPy - BCy * BPx, e2 = CAx * CPy - CAy * CPx;
@@ -639,20 +637,27 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
             const float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
             const float al = aPBC / u.s_area, be = aPCA / u.s_area, ga = 1.0f - al - be;
             const float z = al * u.z0 + be * u.z1 + ga * u.z2;
-            const int li = min(lrow + x, TILE * LDS_STRIDE - 1);
+            const int li = min(yl * LDS_STRIDE + xl, TILE * LDS_STRIDE - 1);
             const float zold = zl[li];
-            const bool inside = rowok & (x <= rx1) & in_tri;
+            const bool inside = rowok & (xl <= x1) & in_tri;
             const bool pass = inside & !(z > zold); // <= passes, NaN passes (src/Rasterizer.cpp:475)
             if (pass) {
               zl[li] = z;
               il[li] = idx | S_CLASS_BIT;
             }
-            any_owner |= pass;
             if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
           }
         }
       }
-#undef SRZ_PICK_SHAPE
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // does any pixel of the tile have an owner?  (only tiles that were hit at all need the 16-words-per-lane scan)
+  bool any_owner = false;
+  if (n_hit_tris) {
+    for (int it = 0; it < 4; ++it) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(&il[(it * 8 + (lane >> 3)) * LDS_STRIDE + (lane & 7) * 4]);
+      any_owner |= (q.x & q.y & q.z & q.w) != NO_TRI;
     }
   }
   __builtin_amdgcn_wave_barrier();
