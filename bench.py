@@ -41,11 +41,11 @@ def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
     for slot, tex in enumerate(wl.texture_arrays):
         oracle.texture_set(slot, tex)
     planes = oracle.new_planes(wl.width, wl.height)
-    rc, threads = oracle.draw_omp(frames[0], planes, band=8)  # warm-up (also first-touch of the planes)
+    rc, threads = oracle.draw_omp(frames[0], planes, band=16)  # warm-up (also first-touch of the planes)
     assert rc == 0
     n, t0 = 0, time.perf_counter()
     while n < max_frames and (time.perf_counter() - t0) < budget_s:
-        rc, threads = oracle.draw_omp(frames[n % len(frames)], planes, band=8)  # FUSED_CLEAR frames: clear + draw
+        rc, threads = oracle.draw_omp(frames[n % len(frames)], planes, band=16)  # FUSED_CLEAR frames: clear + draw
         n += 1
     dt = time.perf_counter() - t0
     t1 = time.perf_counter()
@@ -53,7 +53,7 @@ def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
     single = time.perf_counter() - t1
     return {"value": n / dt, "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} frames of {workload_name} (clear+draw each, rotation 10 deg/frame) in {dt:.1f} s, "
-                      f"OpenMP row bands of 8; single-thread oracle: {1.0 / single:.1f} frames/s",
+                      f"OpenMP row bands of 16 (bbox+cull once per triangle); single-thread oracle: {1.0 / single:.1f} frames/s",
             "host_cpus": os.cpu_count()}
 
 
@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", default="spot_texture_1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)

@@ -509,10 +509,18 @@ static void s_shade(const orc_shade_ctx *sc, const float P[3], const float nrm[3
 /* ================================================================================================
  * draw = TraditionalRasterizer::draw for one scene, rows restricted to [row0,row1)
  * ============================================================================================== */
+/* prep (optional): per-triangle {keep, box} computed once for the whole frame (used by the OpenMP baseline so that the
+ * cull / bbox prologue is not repeated by every row band); indexed by the running triangle number. */
+typedef struct {
+  int keep;
+  orc_box box;
+} orc_prep;
+
 static int draw_rows(const srz_frame *fr, float *zb, float *c0, float *c1, float *c2, int row0, int row1,
-                     srz_stats *st, uint8_t *owned) {
+                     srz_stats *st, uint8_t *owned, const orc_prep *prep) {
   const int W = fr->width, H = fr->height;
   const int unified = (fr->flags & SRZ_UNIFIED) != 0;
+  size_t running = 0;
   for (uint32_t bi = 0; bi < fr->n_batches; ++bi) {
     const srz_batch *b = &fr->batches[bi];
     orc_shade_ctx sc;
@@ -526,6 +534,10 @@ static int draw_rows(const srz_frame *fr, float *zb, float *c0, float *c1, float
     for (uint32_t ti = 0; ti < b->n_tris; ++ti) {
       const srz_tri *t = &b->tris[ti];
       orc_box box;
+      if (prep) {
+        const orc_prep *pp = &prep[running++];
+        if (!pp->keep || pp->box.ey < row0 || pp->box.sy >= row1) continue;
+      }
       if (st && row0 == 0) st->n_tris++;
       if (!tri_box(t, W, H, &box)) {
         if (st && row0 == 0) st->n_culled++;
@@ -624,7 +636,7 @@ int orc_draw(int primitive, const srz_frame *fr, float *z, float *c0, float *c1,
   if (st) memset(st, 0, sizeof *st);
   if (fr->flags & SRZ_FUSED_CLEAR) orc_clear(fr->width, fr->height, z, c0, c1, c2);
   uint8_t *owned = st ? (uint8_t *)calloc((size_t)fr->width * fr->height, 1) : NULL;
-  int rc = draw_rows(fr, z, c0, c1, c2, 0, fr->height, st, owned);
+  int rc = draw_rows(fr, z, c0, c1, c2, 0, fr->height, st, owned, NULL);
   if (owned) {
     for (size_t i = 0; i < (size_t)fr->width * fr->height; ++i) st->visible += owned[i] != 0, st->visible_textured += owned[i] == 2;
     free(owned);
@@ -639,37 +651,55 @@ int orc_draw_rows(const srz_frame *fr, float *z, float *c0, float *c1, float *c2
   if (row1 > fr->height) row1 = fr->height;
   if (fr->flags & SRZ_FUSED_CLEAR)
     for (size_t i = (size_t)row0 * fr->width; i < (size_t)row1 * fr->width; ++i) z[i] = INFINITY, c0[i] = c1[i] = c2[i] = 0.0f;
-  return draw_rows(fr, z, c0, c1, c2, row0, row1, NULL, NULL);
+  return draw_rows(fr, z, c0, c1, c2, row0, row1, NULL, NULL, NULL);
 }
 
 /* CPU baseline: the same per-pixel code, rows dealt in bands of `band` rows to OpenMP threads (per-pixel
  * results depend only on the per-pixel submission order, which every band preserves). Returns threads used. */
 int orc_draw_omp(const srz_frame *fr, float *z, float *c0, float *c1, float *c2, int band, int *threads_used) {
   if (!fr || !z || !c0 || !c1 || !c2 || band <= 0) return SRZ_E_INVALID;
-  const int H = fr->height, nb = (H + band - 1) / band;
+  const int W = fr->width, H = fr->height, nb = (H + band - 1) / band;
+  size_t n_tris = 0;
+  for (uint32_t bi = 0; bi < fr->n_batches; ++bi) n_tris += fr->batches[bi].n_tris;
+  orc_prep *prep = (orc_prep *)malloc(sizeof(orc_prep) * (n_tris ? n_tris : 1));
+  const srz_tri **flat = (const srz_tri **)malloc(sizeof(void *) * (n_tris ? n_tris : 1));
+  if (!prep || !flat) {
+    free(prep), free(flat);
+    return SRZ_E_NOMEM;
+  }
+  size_t k = 0;
+  for (uint32_t bi = 0; bi < fr->n_batches; ++bi)
+    for (uint32_t ti = 0; ti < fr->batches[bi].n_tris; ++ti) flat[k++] = &fr->batches[bi].tris[ti];
   int rc = SRZ_OK, nthreads = 1;
 #ifdef _OPENMP
 #pragma omp parallel
+#endif
   {
+#ifdef _OPENMP
 #pragma omp single
     nthreads = omp_get_num_threads();
+#pragma omp for schedule(static)
+#endif
+    for (long long i = 0; i < (long long)n_tris; ++i) { /* prologue once per triangle: bbox + backface test */
+      prep[i].keep = tri_box(flat[i], W, H, &prep[i].box) && !tri_culled(flat[i], fr->eye);
+    }
+#ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
+#endif
     for (int b = 0; b < nb; ++b) {
       int r0 = b * band, r1 = r0 + band > H ? H : r0 + band;
-      int r = orc_draw_rows(fr, z, c0, c1, c2, r0, r1);
+      if (fr->flags & SRZ_FUSED_CLEAR)
+        for (size_t i = (size_t)r0 * W; i < (size_t)r1 * W; ++i) z[i] = INFINITY, c0[i] = c1[i] = c2[i] = 0.0f;
+      int r = draw_rows(fr, z, c0, c1, c2, r0, r1, NULL, NULL, prep);
       if (r != SRZ_OK) {
+#ifdef _OPENMP
 #pragma omp critical
+#endif
         rc = r;
       }
     }
   }
-#else
-  for (int b = 0; b < nb; ++b) {
-    int r0 = b * band, r1 = r0 + band > H ? H : r0 + band;
-    int r = orc_draw_rows(fr, z, c0, c1, c2, r0, r1);
-    if (r != SRZ_OK) rc = r;
-  }
-#endif
+  free(prep), free(flat);
   if (threads_used) *threads_used = nthreads;
   return rc;
 }
