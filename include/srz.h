@@ -158,6 +158,9 @@ uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *
 int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches);
 int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
 int srz_sync(srz_ctx *ctx);
+/* self-check of the device arithmetic: compares the kernels' short exact reciprocal / square-root sequences with the
+ * IEEE expansions on all 2^32 binary32 operands. out4 = {operands on the fast path, rcp, sqrt, 1/sqrt mismatches} */
+int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
 /* diagnostic only: arm!=0 allocates a per-tile timeline filled by the next srz_frameset_stats; arm==0 copies it out

@@ -498,6 +498,20 @@ int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches) {
   return SRZ_OK;
 }
 
+/* self-check: exhaustive (2^32 operands) comparison of the kernels' short exact rcp / sqrt sequences with the IEEE
+ * expansions. out4 = {fast-path operands, rcp mismatches, sqrt mismatches, 1/sqrt mismatches} */
+int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4) {
+  if (!ctx || !out4) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  launch_verify_fastmath(ctx->d_stats, ctx->stream);
+  unsigned long long h[4];
+  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 4; ++i) out4[i] = h[i];
+  return SRZ_OK;
+}
+
 /* diagnostic: per-tile {start,end (100 MHz wall clock), HW_ID, blocks} of the next stats run; cap = tiles */
 int srz_debug_timeline(srz_ctx *ctx, uint64_t *out, size_t n_tiles, int arm) {
   if (!ctx) return SRZ_E_INVALID;

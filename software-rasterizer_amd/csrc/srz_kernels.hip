@@ -48,20 +48,54 @@ __device__ __forceinline__ float std_clamp(float v, float lo, float hi) { return
 __device__ __forceinline__ float fmsubf(float a, float b, float c) { return __builtin_fmaf(a, b, -c); }
 __device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// ---- exact reciprocal / square root without the compiler's scaling + fix-up scaffolding --------------------------
+// For a normal operand with 2^-100 <= |x| <= 2^100 the short sequences below return EXACTLY the correctly rounded
+// 1/x and sqrt(x) — verified on MI355X against the IEEE expansions for every one of the 3.37e9 binary32 values in that
+// range (k_verify_fastmath, run by tests/test_gpu_fastmath.py).  Operands outside the range (zero, denormal, huge,
+// inf, NaN) take the compiler's full IEEE path, so the functions are drop-in equal to `1.0f/x` and `sqrtf(x)`.
+__device__ __forceinline__ uint32_t f2u_(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ bool fast_range(float x) { return (((f2u_(x) >> 23) & 0xffu) - 27u) <= 200u; }
+__device__ __forceinline__ float rcp_core(float x) { // v_rcp_f32 + one Newton step
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float sqrt_core(float x) { // v_sqrt_f32 corrected by the exact residual
+  float s = __builtin_amdgcn_sqrtf(x), h = 0.5f * __builtin_amdgcn_rsqf(x);
+  return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+}
+// The slow (full IEEE) variants are out-of-line and entered only when SOME lane of the wave has an out-of-range
+// operand (wave-uniform branch: no if-conversion, the long expansions are not even fetched in the common case).
+__device__ __attribute__((noinline)) float rcp_ieee(float x) { return 1.0f / x; }
+__device__ __attribute__((noinline)) float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+__device__ __attribute__((noinline)) float rsqrt2_ieee(float d) { return 1.0f / __builtin_sqrtf(d); }
+__device__ __forceinline__ float rcp_rn(float x) {
+  if (__ballot(!fast_range(x)) == 0ull) return rcp_core(x);
+  return rcp_ieee(x);
+}
+__device__ __forceinline__ float sqrt_rn(float x) {
+  if (__ballot(!(fast_range(x) && x > 0.0f)) == 0ull) return sqrt_core(x);
+  return sqrt_ieee(x);
+}
+// 1.0f / sqrtf(d) with both roundings (sqrt, then reciprocal), as glm::inversesqrt / rcp_ps(sqrt_ps()) compute it
+__device__ __forceinline__ float rsqrt2_rn(float d) {
+  if (__ballot(!(fast_range(d) && d > 0.0f)) == 0ull) return rcp_core(sqrt_core(d)); // sqrt(d) in [2^-50,2^50]: fast range
+  return rsqrt2_ieee(d);
+}
+
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
   float tx = ax * bx, ty = ay * by, tz = az * bz;
   return tx + ty + tz;
 }
 // glm::normalize: v * (1/sqrt(dot(v,v)))
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
-  float is = 1.0f / __builtin_sqrtf(dot3(x, y, z, x, y, z));
+  float is = rsqrt2_rn(dot3(x, y, z, x, y, z));
   x = x * is, y = y * is, z = z * is;
 }
 // NormalSIMD::normalized (src/Tools.cpp:13-24)
 __device__ __forceinline__ void v_normalized(float &x, float &y, float &z) {
-  float len = __builtin_sqrtf(fmaf_(x, x, fmaf_(y, y, z * z)));
+  float len = sqrt_rn(fmaf_(x, x, fmaf_(y, y, z * z)));
   if (len > 0.0f) {
-    float inv = 1.0f / len;
+    float inv = rcp_rn(len);
     x = x * inv, y = y * inv, z = z * inv;
   } else {
     x = y = z = 0.0f;
@@ -97,7 +131,7 @@ struct TriXY {
 };
 __device__ __forceinline__ void tri_consts(TriXY &t) {
   float ABx = t.bx - t.ax, ABy = t.by - t.ay, ACx = t.cx - t.ax, ACy = t.cy - t.ay;
-  t.v_inv = 1.0f / fmsubf(ABx, ACy, ACx * ABy);
+  t.v_inv = rcp_rn(fmsubf(ABx, ACy, ACx * ABy));
   t.s_area = ABx * ACy - ABy * ACx;
 }
 
@@ -263,7 +297,7 @@ __device__ __forceinline__ void v_blinn_phong(float nx, float ny, float nz, cons
                                               float &o2) {
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
   float lx = Lx - px, ly = Ly - py, lz = Lz - pz;
-  float att = 1.0f / __builtin_sqrtf(fmaf_(lx, lx, ly * ly));
+  float att = rsqrt2_rn(fmaf_(lx, lx, ly * ly));
   float d0 = I0 * att, d1 = I1 * att, d2 = I2 * att;
   float hx = lx + (K.eye[0] - px), hy = ly + (K.eye[1] - py), hz = lz + (K.eye[2] - pz);
   v_normalized(hx, hy, hz);
@@ -831,34 +865,43 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
     __syncthreads();
     const uint32_t nV = s_cnt[0], nS = s_cnt[1];
 
-    // ---- 2. dense V pass, dense S pass ------------------------------------------------------------------------------
-    for (uint32_t i = tid; i < nV; i += 256) {
-      const uint32_t p = s_list[i];
-      const uint32_t id = s_ids[p];
-      TriFetch tf;
-      fetch_tri(tris, tri_batch, id, tf);
-      const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-      ShadeDesc sd;
-      sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-      float r0, r1, r2;
-      shade_pixel_v(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
-      s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
-      if (STATS)
-        n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
-    }
-    for (uint32_t i = tid; i < nS; i += 256) {
-      const uint32_t p = s_list[TILE * TILE - 1 - i];
-      const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
-      TriFetch tf;
-      fetch_tri(tris, tri_batch, id, tf);
-      const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-      ShadeDesc sd;
-      sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-      float r0, r1, r2;
-      shade_pixel_s(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
-      s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
-      if (STATS)
-        n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
+    // ---- 2. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
+    //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial ---
+    const uint32_t cV = (nV + 63) >> 6, cS = (nS + 63) >> 6;
+    for (uint32_t c = (uint32_t)wave; c < cV + cS; c += 4) {
+      if (c < cV) {
+        const uint32_t i = c * 64 + lane;
+        if (i < nV) {
+          const uint32_t p = s_list[i];
+          const uint32_t id = s_ids[p];
+          TriFetch tf;
+          fetch_tri(tris, tri_batch, id, tf);
+          const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+          ShadeDesc sd;
+          sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+          float r0, r1, r2;
+          shade_pixel_v(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
+          s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
+          if (STATS)
+            n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
+        }
+      } else {
+        const uint32_t i = (c - cV) * 64 + lane;
+        if (i < nS) {
+          const uint32_t p = s_list[TILE * TILE - 1 - i];
+          const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
+          TriFetch tf;
+          fetch_tri(tris, tri_batch, id, tf);
+          const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+          ShadeDesc sd;
+          sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+          float r0, r1, r2;
+          shade_pixel_s(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
+          s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
+          if (STATS)
+            n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
+        }
+      }
     }
     __syncthreads();
 
@@ -888,6 +931,29 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
       if (n_vis_tex) atomicAdd(&a.stats[ST_VISIBLE_TEX], n_vis_tex);
     }
   }
+}
+
+// Exhaustive check of the short exact sequences above against the IEEE expansions: all 2^32 bit patterns.
+// out[0] = operands tested on the fast path, out[1..3] = mismatches of rcp_rn / sqrt_rn / rsqrt2_rn (must be 0).
+__global__ void k_verify_fastmath(unsigned long long *out) {
+  unsigned long long bad0 = 0, bad1 = 0, bad2 = 0, n = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __builtin_bit_cast(float, (uint32_t)i);
+    const float a = rcp_rn(x), ra = 1.0f / x;
+    bad0 += f2u_(a) != f2u_(ra);
+    const float b = sqrt_rn(x), rb = __builtin_sqrtf(x);
+    bad1 += f2u_(b) != f2u_(rb);
+    const float c = rsqrt2_rn(x), rc = 1.0f / rb;
+    bad2 += f2u_(c) != f2u_(rc);
+    n += fast_range(x);
+  }
+  if (n) atomicAdd(&out[0], n);
+  if (bad0) atomicAdd(&out[1], bad0);
+  if (bad1) atomicAdd(&out[2], bad1);
+  if (bad2) atomicAdd(&out[3], bad2);
+}
+void launch_verify_fastmath(unsigned long long *d_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_verify_fastmath, dim3(8192), dim3(256), 0, s, d_out);
 }
 
 // BGR u8 (row_stride bytes per row) → one dword per texel

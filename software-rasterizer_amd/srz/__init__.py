@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline"]
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath"]
 
 
 class SrzError(RuntimeError):
@@ -57,6 +57,7 @@ def lib():
         L.srz_set_kernel_timing.argtypes = [vp, C.c_int]
         L.srz_sync.argtypes = [vp]
         L.srz_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.srz_verify_fastmath.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_debug_timeline.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_int]
         _lib = L
     return _lib
@@ -154,6 +155,11 @@ class Context:
         ms, n = (C.c_double * 4)(), C.c_int()
         self._check(lib().srz_kernel_time_ms(self.h, 1 if reset else 0, ms, C.byref(n)))
         return {"bin_ms": ms[0], "raster_ms": ms[1], "shade_ms": ms[2], "total_ms": ms[3], "launches": n.value}
+
+    def verify_fastmath(self):
+        out = (C.c_uint64 * 4)()
+        self._check(lib().srz_verify_fastmath(self.h, out))
+        return [int(x) for x in out]
 
     def debug_timeline(self, n_tiles, arm):
         if arm:
