@@ -194,7 +194,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t), s));
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
-  launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, s);
+  launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, fs->max_tris, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
   launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));

@@ -94,7 +94,7 @@ struct RenderArgs {
 
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
 void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
-                  hipStream_t s);
+                  uint32_t max_tris, hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s);
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s);
 void launch_verify_fastmath(unsigned long long *d_out4, hipStream_t s);

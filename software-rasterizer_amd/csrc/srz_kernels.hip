@@ -212,70 +212,120 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
 }
 
 // ================================================================================================================
-// k_bands — one wave per (frame, local band): ordered ballot compaction of the triangles whose bbox touches the band.
-// Hits are queued (indices, LDS) and flushed 64 at a time: the flush gathers positions + bbox with independent loads
-// (one memory round trip per 64 hits) and writes coalesced 48-byte RasterRec entries.
+// k_bands — one WORKGROUP of 16 waves per (frame, local band): ordered compaction of the triangles whose bbox touches
+// the band into the band's RasterRec list.  Submission order is preserved by construction (no atomics, no sort):
+//   pass 1  the 64-triangle chunks are dealt round-robin to the waves; each wave ballots its chunks and stores the
+//           per-chunk hit count in LDS
+//   scan    exclusive prefix over the chunk counts (wave 0)
+//   pass 2  each wave revisits its chunks; a hit's output slot = chunk offset + rank inside the chunk.  Hits are queued
+//           (index, slot) in LDS and flushed 64 at a time so that the gather of positions + bbox is one round trip of
+//           independent loads per 64 hits, written as 48-byte RasterRec.
+// Lists longer than BANDS_MAX_CHUNKS*64 triangles are handled in super-blocks with a running base.
 // ================================================================================================================
-__global__ __launch_bounds__(256) void k_bands(RenderArgs a, RasterRec *band_recs, uint32_t *band_count) {
-  __shared__ uint32_t s_q[WAVES_PER_WG][128];
+constexpr int BANDS_MAX_WAVES = 16;
+constexpr int BANDS_MAX_CHUNKS = 2048; // chunk counters held in LDS per super-block (= 131072 triangles)
+
+// launched with 4..16 waves per workgroup (small streams do not pay for idle waves) and
+// dynamic LDS = (3 * chunks_cap + 256 * waves + 2) dwords: [hit masks (u64) | offsets | per-wave index/slot queues | total]
+__global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, RasterRec *band_recs, uint32_t *band_count,
+                                                                uint32_t chunks_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  const int BANDS_WAVES = (int)(blockDim.x >> 6);
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_dyn); // pass 1: hit mask of every chunk
+  uint32_t *s_off = s_dyn + 2 * chunks_cap;                                   // after the scan: exclusive offset per chunk
+  uint32_t *s_q = s_off + chunks_cap;
+  uint32_t &s_total = s_q[256 * BANDS_WAVES];
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t lb = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
-  if (lb >= fd->n_local_bands) return;
+  const uint32_t lb = blockIdx.x;
+  if (lb >= fd->n_local_bands) return; // workgroup-uniform
   const uint32_t n_tris = fd->n_tris;
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
   RasterRec *out = band_recs + fd->list_off + (uint64_t)lb * n_tris;
   const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
   const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
-  uint32_t *q = s_q[wave];
-  uint32_t cursor = 0, nq = 0;
-  auto flush = [&](uint32_t n) { // n <= 64 queued indices → records
+  uint32_t *qi = s_q + 256 * wave, *qp = qi + 128;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  auto hit_mask = [&](uint32_t chunk) -> unsigned long long {
+    const uint32_t t = chunk * 64 + lane;
+    bool hit = false;
+    if (t < n_tris) {
+      const u32x2 r = bbox[t];
+      const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
+      hit = sx <= ex && sy <= y1 && ey >= y0;
+    }
+    return __ballot(hit);
+  };
+  auto flush = [&](uint32_t n) { // n <= 64 queued (index, slot) pairs → records
     if ((uint32_t)lane < n) {
-      const uint32_t t = q[lane];
+      const uint32_t t = qi[lane], pos = qp[lane];
       const u32x2 r = bbox[t];
       const SRZ_CAS float *p = &tris[t].pos[0][0];
       RasterRec rec;
       rec.ax = p[0], rec.ay = p[1], rec.z0 = p[2], rec.bx = p[3], rec.by = p[4], rec.z1 = p[5];
       rec.cx = p[6], rec.cy = p[7], rec.z2 = p[8];
       rec.bbx = r.x, rec.bby = r.y, rec.idx = t;
-      out[cursor + lane] = rec;
+      out[pos] = rec;
     }
-    cursor += n;
   };
-  u32x2 nxt = {1u, 0u}, nxt2 = {1u, 0u}; // two chunks of bbox records in flight (empty box: sx=1 > ex=0)
-  if ((uint32_t)lane < n_tris) nxt = bbox[lane];
-  if ((uint32_t)lane + 64 < n_tris) nxt2 = bbox[lane + 64];
-  for (uint32_t base = 0; base < n_tris; base += 64) {
-    const uint32_t t = base + lane;
-    const u32x2 r = nxt;
-    nxt = nxt2;
-    nxt2 = u32x2{1u, 0u};
-    if (t + 128 < n_tris) nxt2 = bbox[t + 128];
-    bool hit = false;
-    {
-      const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
-      hit = t < n_tris && sx <= ex && sy <= y1 && ey >= y0;
+  const uint32_t n_chunks = (n_tris + 63) / 64;
+  uint32_t base = 0; // records written by earlier super-blocks
+  for (uint32_t sb = 0; sb < n_chunks; sb += chunks_cap) {
+    const uint32_t nc = min(chunks_cap, n_chunks - sb);
+    // ---- pass 1: per-chunk hit counts ------------------------------------------------------------------------------
+    for (uint32_t c = (uint32_t)wave; c < nc; c += BANDS_WAVES) {
+      const unsigned long long m = hit_mask(sb + c);
+      if (lane == 0) s_mask[c] = m, s_off[c] = (uint32_t)__popcll(m);
     }
-    const unsigned long long m = __ballot(hit);
-    if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = t;
-    nq += (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    if (nq >= 64) {
-      flush(64);
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t rest = nq - 64; // < 64
-      uint32_t mv = 0;
-      if ((uint32_t)lane < rest) mv = q[64 + lane];
-      __builtin_amdgcn_wave_barrier();
-      if ((uint32_t)lane < rest) q[lane] = mv;
-      nq = rest;
-      __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    // ---- scan (wave 0): exclusive prefix of the counts -------------------------------------------------------------
+    if (wave == 0) {
+      uint32_t run = base;
+      for (uint32_t c0 = 0; c0 < nc; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < nc ? s_off[c] : 0u;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = __shfl_up(incl, o);
+          if (lane >= o) incl += up;
+        }
+        if (c < nc) s_off[c] = run + incl - v;
+        run += __shfl(incl, 63);
+      }
+      if (lane == 0) s_total = run;
     }
+    __syncthreads();
+    // ---- pass 2: ordered fill ----------------------------------------------------------------------------------------
+    uint32_t nq = 0;
+    for (uint32_t c = (uint32_t)wave; c < nc; c += BANDS_WAVES) {
+      const unsigned long long m = s_mask[c]; // (this wave wrote it in pass 1)
+      if (m == 0ull) continue;
+      if ((m >> lane) & 1ull) {
+        const uint32_t k = nq + (uint32_t)__popcll(m & lt);
+        qi[k] = (sb + c) * 64 + lane;
+        qp[k] = s_off[c] + (uint32_t)__popcll(m & lt);
+      }
+      nq += (uint32_t)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (nq >= 64) {
+        flush(64);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rest = nq - 64; // < 64
+        uint32_t mi = 0, mp = 0;
+        if ((uint32_t)lane < rest) mi = qi[64 + lane], mp = qp[64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rest) qi[lane] = mi, qp[lane] = mp;
+        nq = rest;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (nq) flush(nq);
+    base = s_total;
+    __syncthreads(); // s_off / s_total are reused by the next super-block
   }
-  if (nq) flush(nq);
-  if (lane == 0) band_count[fd->count_off + lb] = cursor;
+  if (threadIdx.x == 0) band_count[fd->count_off + lb] = base;
 }
 
 // ================================================================================================================
@@ -978,10 +1028,14 @@ void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool sta
 }
 
 void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
-                  hipStream_t s) {
+                  uint32_t max_tris, hipStream_t s) {
   if (n_frames <= 0 || max_local_bands == 0) return;
-  dim3 grid((max_local_bands + WAVES_PER_WG - 1) / WAVES_PER_WG, n_frames);
-  hipLaunchKernelGGL(k_bands, grid, dim3(256), 0, s, a, band_recs, band_count);
+  dim3 grid(max_local_bands, n_frames);
+  const uint32_t n_chunks = (max_tris + 63) / 64;
+  const uint32_t cap = n_chunks < 1 ? 1 : (n_chunks > (uint32_t)BANDS_MAX_CHUNKS ? (uint32_t)BANDS_MAX_CHUNKS : n_chunks);
+  const int waves = n_chunks <= 256 ? 4 : (n_chunks <= 1024 ? 8 : BANDS_MAX_WAVES);
+  const size_t lds = sizeof(uint32_t) * (3u * (size_t)cap + 256u * waves + 2u);
+  hipLaunchKernelGGL(k_bands, grid, dim3(64 * waves), lds, s, a, band_recs, band_count, cap);
 }
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s) {
