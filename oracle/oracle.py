@@ -30,7 +30,7 @@ def lib():
         fp = C.POINTER(C.c_float)
         L.orc_draw.argtypes = [C.c_int, C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
         L.orc_draw_rows.argtypes = [C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.c_int, C.c_int]
-        L.orc_draw_omp.argtypes = [C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.c_int, C.POINTER(C.c_int)]
+        L.orc_draw_omp.argtypes = [C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.orc_texture_set.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_vertex_stage.argtypes = [fp, C.c_void_p, C.c_uint32, fp, fp, fp, fp, C.c_float, C.c_float, C.c_void_p]
         L.orc_vertex_stage.restype = None
@@ -143,10 +143,10 @@ def draw_rows(frame, planes, row0, row1):
     return lib().orc_draw_rows(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(row0), int(row1))
 
 
-def draw_omp(frame, planes, band=16):
+def draw_omp(frame, planes, band=16, threads=0):
     z, c0, c1, c2 = planes
     n = C.c_int(0)
-    rc = lib().orc_draw_omp(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(band), C.byref(n))
+    rc = lib().orc_draw_omp(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(band), C.byref(n), int(threads))
     return rc, n.value
 
 

@@ -656,8 +656,11 @@ int orc_draw_rows(const srz_frame *fr, float *z, float *c0, float *c1, float *c2
 
 /* CPU baseline: the same per-pixel code, rows dealt in bands of `band` rows to OpenMP threads (per-pixel
  * results depend only on the per-pixel submission order, which every band preserves). Returns threads used. */
-int orc_draw_omp(const srz_frame *fr, float *z, float *c0, float *c1, float *c2, int band, int *threads_used) {
+int orc_draw_omp(const srz_frame *fr, float *z, float *c0, float *c1, float *c2, int band, int *threads_used, int num_threads) {
   if (!fr || !z || !c0 || !c1 || !c2 || band <= 0) return SRZ_E_INVALID;
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
   const int W = fr->width, H = fr->height, nb = (H + band - 1) / band;
   size_t n_tris = 0;
   for (uint32_t bi = 0; bi < fr->n_batches; ++bi) n_tris += fr->batches[bi].n_tris;

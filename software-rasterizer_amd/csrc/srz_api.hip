@@ -2,6 +2,7 @@
 // No CPU fallback exists: without a usable gfx950 device every compute entry point returns SRZ_E_NODEVICE.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -345,7 +346,7 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
     d.p = fr.p, d.kh = fr.kh, d.kn = fr.kn;
     d.n_lights = fr.n_lights, d.light_off = (uint32_t)light_off;
     d.tri_off = (uint32_t)tri_off, d.n_batches = fr.n_batches, d.batch_off = (uint32_t)batch_off;
-    d.flags = fr.flags;
+    d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR);
     uint64_t nt = 0;
     for (uint32_t b = 0; b < fr.n_batches; ++b) {
       const srz_batch &sb = fr.batches[b];
@@ -441,6 +442,9 @@ int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_
   if (((uintptr_t)d_out & 15u) != 0) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: output must be 16-byte aligned");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  // bits 8..15 are kernel-ablation switches for the dev probes (tests/perf_probe.py); honoured only under SRZ_DEBUG_FLAGS
+  static const bool dbg = getenv("SRZ_DEBUG_FLAGS") != nullptr;
+  flags &= (SRZ_UNIFIED | SRZ_FUSED_CLEAR) | (dbg ? 0xff00u : 0u);
   return render_impl(ctx, fs, (float *)d_out, flags, s, false);
 }
 

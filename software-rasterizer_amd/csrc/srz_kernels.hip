@@ -924,13 +924,18 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
         if (i < nV) {
           const uint32_t p = s_list[i];
           const uint32_t id = s_ids[p];
+          float r0 = 1.f, r1 = 2.f, r2 = 3.f;
+          ShadeDesc sd;
+          sd.shader = 0;
+          if (!(flags & 0x800u)) {
           TriFetch tf;
           fetch_tri(tris, tri_batch, id, tf);
           const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-          ShadeDesc sd;
           sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-          float r0, r1, r2;
+          if (flags & 0x1000u) r0 = tf.q0.x + tf.q5.w + (float)tf.batch, r1 = tf.q3.y + tf.q2.x + tf.q1.x, r2 = tf.q4.z + (float)sd.tw;
+          else
           shade_pixel_v(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
+          }
           s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
           if (STATS)
             n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);

@@ -1,7 +1,10 @@
 """Dev tool (not a test, not the bench): time the frameset path on the GPU for a config.
 usage: python tests/perf_probe.py [config=2] [frames=64] [iters=20]"""
+import os
 import sys
 import time
+
+os.environ.setdefault('SRZ_DEBUG_FLAGS', '1')
 
 import conftest  # noqa: F401  (sys.path)
 import numpy as np

@@ -1,5 +1,7 @@
 """Dev tool: per-tile timeline of k_raster (stats variant) → concurrency analysis."""
+import os
 import sys
+os.environ.setdefault("SRZ_DEBUG_FLAGS", "1")
 import conftest  # noqa
 import numpy as np
 import torch
