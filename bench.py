@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", default="spot_texture_1024")
+    ap.add_argument("--scope", choices=["raster", "draw"], default="raster",
+                    help="raster: post-MVP triangle streams resident in HBM (BASELINE's hot path); "
+                         "draw: meshes + per-frame matrices resident, the vertex stage (k_vertex) is timed too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     args = ap.parse_args()
@@ -106,6 +109,11 @@ def main():
     frames = [uniq[i % len(uniq)] for i in range(n_frames)]
     ctx = srz.Context(local_rank, rank, world)
     wl.upload_textures(ctx)
+    n_tris_frame = frames[0].n_tris
+    if args.scope == "draw":  # same frames, given as meshes + matrices: the device runs the vertex stage every step
+        wl.upload_meshes(ctx)
+        suniq = [wl.scene_frame(i) for i in range(min(n_frames, 36))]
+        frames = [suniq[i % len(suniq)] for i in range(n_frames)]
     fs = ctx.frameset(frames)
     stats = fs.stats()  # counting variant of the kernels, run once, outside the timed region
     if world > 1:
@@ -170,7 +178,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": fs.width, "height": fs.height,
                        "frames_per_step": n_frames, "frames_per_step_per_gpu": args.frames,
-                       "triangles_per_frame": frames[0].n_tris, "lights": 2,
+                       "triangles_per_frame": n_tris_frame, "lights": 2, "scope": args.scope,
                        "sharding": "whole frames on 1 GPU" if world == 1 else
                        f"32-row bands round-robin over {world} GPUs + RCCL all-gather + de-interleave (timed)"},
             "mfragments_per_sec": frag_total / fs.n_frames * fps / 1e6,

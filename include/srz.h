@@ -108,6 +108,36 @@ typedef struct srz_stats {
   uint64_t visible_textured; /* of those, pixels whose owner's shader fetches the texture (B_tex of the roofline) */
 } srz_stats;
 
+/* ---- device vertex stage (= Scene::loadTriangleStream, src/Scene.cpp:903-964, run on the GPU) ------------------
+ * Instead of post-MVP triangles the caller hands over meshes (uploaded once) and, per frame, one srz_mesh_draw per mesh:
+ * the two matrices loadTriangleStream builds (:922-923) and the depth remap (:279-280).  Matrices are column-major
+ * (glm layout, m[col*4+row]). */
+typedef struct srz_vertex { /* = SoftRasterizer::Vertex {position, normal, texCoord} (include/object/Object.hpp:17-31) */
+  float pos[3];
+  float nrm[3];
+  float uv[2];
+} srz_vertex; /* 32 B */
+
+typedef struct srz_mesh_draw {
+  int32_t mesh_id;     /* srz_mesh_upload slot */
+  int32_t shader;      /* SRZ_SHADER_* of the Shader bound to the mesh */
+  int32_t tex_id;      /* texture slot, ignored by NORMAL / PHONG */
+  int32_t _pad;
+  float ndc_mvp[16];   /* m_ndcToScreenMatrix * m_projection * m_view * modelMatrix */
+  float normal_m[16];  /* transpose(inverse(modelMatrix)) */
+} srz_mesh_draw;
+
+typedef struct srz_scene_frame {
+  int32_t width, height;
+  float eye[3], ka[3], ks[3];
+  float p, kh, kn;
+  float zscale, zoffset; /* (far-near)/2, (far+near)/2 */
+  uint32_t n_lights, n_draws;
+  const srz_light *lights;
+  const srz_mesh_draw *draws; /* in mesh registration order = batch order */
+  uint32_t flags, _pad;
+} srz_scene_frame;
+
 typedef struct srz_ctx srz_ctx;
 typedef struct srz_frameset srz_frameset;
 
@@ -126,6 +156,10 @@ int srz_set_shard(srz_ctx *ctx, int rank, int world);
  *      src/TextureLoader.cpp:3-12).  row_stride in bytes. Slots 0..63. ------------------- */
 int srz_texture_upload(srz_ctx *ctx, int tex_id, const uint8_t *bgr, int w, int h, int row_stride);
 
+/* ---- mesh = Mesh::vertices + Mesh::faces (include/object/Mesh.hpp:52-57), slots 0..255; faces = 3 indices each ---- */
+int srz_mesh_upload(srz_ctx *ctx, int mesh_id, const srz_vertex *verts, uint32_t n_verts, const uint32_t *faces,
+                    uint32_t n_faces);
+
 /* ---- draw = TraditionalRasterizer::draw(TRIANGLES) for one scene ----------------------
  * z/c0/c1/c2: W*H floats each, in/out (m_zBuffer, m_channels[0..2]); draw never clears unless
  * SRZ_FUSED_CLEAR.  primitive: LINES is accepted and rasterised as triangles exactly like the
@@ -142,6 +176,12 @@ int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, floa
  * bands_per_rank*32, zero-padded).  d_out is a DEVICE pointer (e.g. a torch tensor's data_ptr),
  * stream a hipStream_t (NULL = the ctx's own stream).  The call is asynchronous on that stream. */
 int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out);
+/* Same, but the frames are given as meshes + matrices: every srz_frameset_render first runs the vertex stage on the
+ * device (k_vertex) to produce the post-MVP stream, i.e. it times the reference's whole draw(). */
+int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frames, srz_frameset **out);
+/* draw() for one scene with the vertex stage on the device (host planes in/out, like srz_draw) */
+int srz_draw_scene(srz_ctx *ctx, int primitive, const srz_scene_frame *frame, float *z, float *c0, float *c1, float *c2,
+                   srz_stats *stats);
 void srz_frameset_destroy(srz_ctx *ctx, srz_frameset *fs);
 int srz_frameset_local_rows(const srz_ctx *ctx, const srz_frameset *fs);
 size_t srz_frameset_out_bytes(const srz_ctx *ctx, const srz_frameset *fs);

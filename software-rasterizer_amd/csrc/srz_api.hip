@@ -29,6 +29,11 @@ struct srz_ctx {
   uint32_t *d_texmem[MAX_TEX];
   TexDesc *d_tex = nullptr;
   unsigned long long *d_stats = nullptr;
+  struct MeshSlot {
+    srz_vertex *d_verts = nullptr;
+    uint32_t *d_faces = nullptr;
+    uint32_t n_verts = 0, n_faces = 0;
+  } mesh[MAX_MESH];
   bool timing = false;
   std::vector<EventPair> ev_pool, ev_used;
   double acc_ms[4] = {0, 0, 0, 0}; // bin, raster, shade, total
@@ -57,6 +62,8 @@ struct srz_frameset {
   uint32_t *d_band_count = nullptr;
   uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr;
   ShadeDescG *d_sdesc = nullptr;
+  DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
+  uint32_t n_draws = 0, max_faces = 0;
   uint64_t sdesc_version = 0;
   uint32_t tiles_x = 0, max_tiles = 0;
   bool have_stats = false;
@@ -101,6 +108,7 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_worklist);
   (void)hipFree(fs->d_work_count);
   (void)hipFree(fs->d_sdesc);
+  (void)hipFree(fs->d_draws);
   (void)hipFree(fs->d_band_count);
 }
 
@@ -194,6 +202,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t), s));
+  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
   launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, fs->max_tris, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
@@ -268,6 +277,7 @@ void srz_destroy(srz_ctx *ctx) {
   for (auto &ep : ctx->ev_used) ctx->ev_pool.push_back(ep);
   for (auto &ep : ctx->ev_pool) (void)hipEventDestroy(ep.t0), (void)hipEventDestroy(ep.t1), (void)hipEventDestroy(ep.t2), (void)hipEventDestroy(ep.t3);
   for (int i = 0; i < MAX_TEX; ++i) (void)hipFree(ctx->d_texmem[i]);
+  for (int i = 0; i < MAX_MESH; ++i) (void)hipFree(ctx->mesh[i].d_verts), (void)hipFree(ctx->mesh[i].d_faces);
   (void)hipFree(ctx->d_tex);
   (void)hipFree(ctx->d_stats);
   (void)hipStreamDestroy(ctx->stream);
@@ -315,7 +325,7 @@ int srz_texture_upload(srz_ctx *ctx, int tex_id, const uint8_t *bgr, int w, int 
   return SRZ_OK;
 }
 
-int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out) {
+static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out, bool copy_tris) {
   if (!ctx) return SRZ_E_INVALID;
   if (!out) return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: out is NULL");
   *out = nullptr;
@@ -350,7 +360,7 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
     uint64_t nt = 0;
     for (uint32_t b = 0; b < fr.n_batches; ++b) {
       const srz_batch &sb = fr.batches[b];
-      if (sb.n_tris && !sb.tris) return bad("batch with null triangle pointer");
+      if (copy_tris && sb.n_tris && !sb.tris) return bad("batch with null triangle pointer");
       if (sb.shader < SRZ_SHADER_NORMAL || sb.shader > SRZ_SHADER_BUMP) return bad("unknown shader type");
       fs->h_batches.push_back(BatchDesc{sb.shader, sb.tex_id, (uint32_t)nt, sb.n_tris});
       nt += sb.n_tris;
@@ -367,7 +377,7 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
   fs->total_tris = tri_off, fs->total_lights = light_off;
 
   // stage host copies (pinned not needed: one-time upload)
-  std::vector<srz_tri> h_tris((size_t)tri_off);
+  std::vector<srz_tri> h_tris(copy_tris ? (size_t)tri_off : 0);
   std::vector<uint16_t> h_tb((size_t)tri_off);
   std::vector<srz_light> h_lights((size_t)light_off);
   for (int f = 0; f < n_frames; ++f) {
@@ -376,7 +386,7 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
     size_t o = d.tri_off;
     for (uint32_t b = 0; b < fr.n_batches; ++b) {
       const srz_batch &sb = fr.batches[b];
-      if (sb.n_tris) std::memcpy(&h_tris[o], sb.tris, sizeof(srz_tri) * sb.n_tris);
+      if (copy_tris && sb.n_tris) std::memcpy(&h_tris[o], sb.tris, sizeof(srz_tri) * sb.n_tris);
       std::fill(h_tb.begin() + o, h_tb.begin() + o + sb.n_tris, (uint16_t)b);
       o += sb.n_tris;
     }
@@ -402,7 +412,7 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
   FS_TRY(dev_alloc((void **)&fs->d_band_count, sizeof(uint32_t) * count_off));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
   if (tri_off) {
-    FS_TRY(hipMemcpy(fs->d_tris, h_tris.data(), sizeof(srz_tri) * tri_off, hipMemcpyHostToDevice));
+    if (copy_tris) FS_TRY(hipMemcpy(fs->d_tris, h_tris.data(), sizeof(srz_tri) * tri_off, hipMemcpyHostToDevice));
     FS_TRY(hipMemcpy(fs->d_tri_batch, h_tb.data(), sizeof(uint16_t) * tri_off, hipMemcpyHostToDevice));
   }
   if (!fs->h_batches.empty())
@@ -414,6 +424,89 @@ int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz
     delete fs;
     return fail(ctx, e == hipErrorOutOfMemory ? SRZ_E_NOMEM : SRZ_E_NODEVICE,
                 std::string("srz_frameset_create: ") + hipGetErrorString(e));
+  }
+  *out = fs;
+  return SRZ_OK;
+}
+
+int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out) {
+  return build_frameset(ctx, frames, n_frames, out, true);
+}
+
+int srz_mesh_upload(srz_ctx *ctx, int mesh_id, const srz_vertex *verts, uint32_t n_verts, const uint32_t *faces, uint32_t n_faces) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (mesh_id < 0 || mesh_id >= MAX_MESH || !verts || !faces || n_verts == 0) return fail(ctx, SRZ_E_INVALID, "srz_mesh_upload: bad arguments");
+  for (uint32_t i = 0; i < 3u * n_faces; ++i)
+    if (faces[i] >= n_verts) return fail(ctx, SRZ_E_INVALID, "srz_mesh_upload: face index out of range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  srz_ctx::MeshSlot m;
+  HIP_TRY(ctx, hipMalloc(&m.d_verts, sizeof(srz_vertex) * n_verts));
+  hipError_t e = hipMalloc(&m.d_faces, sizeof(uint32_t) * 3 * (n_faces ? n_faces : 1));
+  if (e == hipSuccess) e = hipMemcpy(m.d_verts, verts, sizeof(srz_vertex) * n_verts, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_faces) e = hipMemcpy(m.d_faces, faces, sizeof(uint32_t) * 3 * n_faces, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(m.d_verts), (void)hipFree(m.d_faces);
+    return fail(ctx, SRZ_E_NOMEM, std::string("srz_mesh_upload: ") + hipGetErrorString(e));
+  }
+  m.n_verts = n_verts, m.n_faces = n_faces;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->mesh[mesh_id].d_verts), (void)hipFree(ctx->mesh[mesh_id].d_faces);
+  ctx->mesh[mesh_id] = m;
+  return SRZ_OK;
+}
+
+int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frames, srz_frameset **out) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!out) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_create: out is NULL");
+  *out = nullptr;
+  if (!frames || n_frames <= 0) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_create: no frames");
+  // describe every frame as an srz_frame whose batches carry sizes only; the triangles are produced by k_vertex
+  std::vector<srz_frame> fr((size_t)n_frames);
+  std::vector<std::vector<srz_batch>> batches((size_t)n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    const srz_scene_frame &sf = frames[f];
+    if (sf.n_draws && !sf.draws) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_create: null draws");
+    for (uint32_t d = 0; d < sf.n_draws; ++d) {
+      const srz_mesh_draw &dr = sf.draws[d];
+      if (dr.mesh_id < 0 || dr.mesh_id >= MAX_MESH || !ctx->mesh[dr.mesh_id].d_verts)
+        return fail(ctx, SRZ_E_INVALID, "srz_sceneset_create: draw names a mesh slot that was never uploaded");
+      srz_batch b{};
+      b.shader = dr.shader, b.tex_id = dr.tex_id, b.n_tris = ctx->mesh[dr.mesh_id].n_faces, b.tris = nullptr;
+      batches[f].push_back(b);
+    }
+    srz_frame &o = fr[f];
+    o = srz_frame{};
+    o.width = sf.width, o.height = sf.height;
+    std::memcpy(o.eye, sf.eye, sizeof o.eye), std::memcpy(o.ka, sf.ka, sizeof o.ka), std::memcpy(o.ks, sf.ks, sizeof o.ks);
+    o.p = sf.p, o.kh = sf.kh, o.kn = sf.kn;
+    o.n_lights = sf.n_lights, o.lights = sf.lights;
+    o.n_batches = sf.n_draws, o.batches = batches[f].data();
+    o.flags = sf.flags;
+  }
+  srz_frameset *fs = nullptr;
+  int rc = build_frameset(ctx, fr.data(), n_frames, &fs, false);
+  if (rc) return rc;
+  std::vector<DrawDesc> h;
+  for (int f = 0; f < n_frames; ++f) {
+    uint32_t first = fs->h_frames[f].tri_off;
+    for (uint32_t d = 0; d < frames[f].n_draws; ++d) {
+      const srz_mesh_draw &dr = frames[f].draws[d];
+      const srz_ctx::MeshSlot &m = ctx->mesh[dr.mesh_id];
+      DrawDesc dd{};
+      dd.verts = m.d_verts, dd.faces = m.d_faces, dd.n_faces = m.n_faces, dd.tri_off = first;
+      dd.zscale = frames[f].zscale, dd.zoffset = frames[f].zoffset;
+      std::memcpy(dd.ndc_mvp, dr.ndc_mvp, sizeof dd.ndc_mvp), std::memcpy(dd.normal_m, dr.normal_m, sizeof dd.normal_m);
+      h.push_back(dd);
+      first += m.n_faces;
+      fs->max_faces = std::max(fs->max_faces, m.n_faces);
+    }
+  }
+  fs->n_draws = (uint32_t)h.size();
+  hipError_t e = hipMalloc(&fs->d_draws, sizeof(DrawDesc) * std::max<size_t>(h.size(), 1));
+  if (e == hipSuccess && !h.empty()) e = hipMemcpy(fs->d_draws, h.data(), sizeof(DrawDesc) * h.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    srz_frameset_destroy(ctx, fs);
+    return fail(ctx, SRZ_E_NOMEM, std::string("srz_sceneset_create: ") + hipGetErrorString(e));
   }
   *out = fs;
   return SRZ_OK;
@@ -547,17 +640,19 @@ int srz_sync(srz_ctx *ctx) {
   return SRZ_OK;
 }
 
-int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, float *c0, float *c1, float *c2,
-             srz_stats *stats) {
+static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const srz_scene_frame *scene, float *z, float *c0,
+                     float *c1, float *c2, srz_stats *stats) {
   if (!ctx) return SRZ_E_INVALID;
   if (primitive != SRZ_PRIMITIVE_LINES && primitive != SRZ_PRIMITIVE_TRIANGLES)
     return fail(ctx, SRZ_E_PRIMITIVE, "Primitive Type is not supported!");
-  if (!frame || !z || !c0 || !c1 || !c2) return fail(ctx, SRZ_E_INVALID, "srz_draw: null argument");
+  if ((!frame && !scene) || !z || !c0 || !c1 || !c2) return fail(ctx, SRZ_E_INVALID, "srz_draw: null argument");
   if (ctx->shard_world != 1) return fail(ctx, SRZ_E_INVALID, "srz_draw: whole-frame draw needs an unsharded ctx (srz_set_shard(ctx,0,1))");
   srz_frameset *fs = nullptr;
-  int rc = srz_frameset_create(ctx, frame, 1, &fs);
+  int rc = frame ? srz_frameset_create(ctx, frame, 1, &fs) : srz_sceneset_create(ctx, scene, 1, &fs);
   if (rc) return rc;
-  const size_t plane = (size_t)frame->width * frame->height, pb = plane * sizeof(float);
+  const int W = frame ? frame->width : scene->width, H = frame ? frame->height : scene->height;
+  const uint32_t fflags = frame ? frame->flags : scene->flags;
+  const size_t plane = (size_t)W * H, pb = plane * sizeof(float);
   float *d_out = nullptr;
   hipError_t e = hipMalloc(&d_out, 4 * pb);
   if (e != hipSuccess) {
@@ -565,7 +660,7 @@ int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, floa
     return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc failed");
   }
   hipStream_t s = ctx->stream;
-  const bool fused = (frame->flags & SRZ_FUSED_CLEAR) != 0;
+  const bool fused = (fflags & SRZ_FUSED_CLEAR) != 0;
   float *host[4] = {z, c0, c1, c2};
   if (!fused)
     for (int p = 0; p < 4 && e == hipSuccess; ++p) e = hipMemcpyAsync(d_out + p * plane, host[p], pb, hipMemcpyHostToDevice, s);
@@ -580,6 +675,18 @@ int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, floa
   srz_frameset_destroy(ctx, fs);
   if (e != hipSuccess) return fail(ctx, SRZ_E_NODEVICE, std::string("srz_draw: ") + hipGetErrorString(e));
   return rc;
+}
+
+int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, float *c0, float *c1, float *c2,
+             srz_stats *stats) {
+  if (ctx && !frame) return fail(ctx, SRZ_E_INVALID, "srz_draw: null argument");
+  return draw_impl(ctx, primitive, frame, nullptr, z, c0, c1, c2, stats);
+}
+
+int srz_draw_scene(srz_ctx *ctx, int primitive, const srz_scene_frame *frame, float *z, float *c0, float *c1, float *c2,
+                   srz_stats *stats) {
+  if (ctx && !frame) return fail(ctx, SRZ_E_INVALID, "srz_draw_scene: null argument");
+  return draw_impl(ctx, primitive, nullptr, frame, z, c0, c1, c2, stats);
 }
 
 } // extern "C"

@@ -16,6 +16,7 @@ constexpr int RASTER_WAVES = 1;      // k_raster: ONE wave (= one tile) per work
 constexpr int LDS_STRIDE = 40;       // padded LDS row stride in dwords: 4 consecutive rows x 8 columns hit 32 distinct banks
 constexpr uint32_t NO_TRI = 0xffffffffu;
 constexpr int MAX_TEX = 64;
+constexpr int MAX_MESH = 256;
 
 // Screen-space bounding box of a surviving triangle (Triangle::calcBoundingBox, src/Triangle.cpp:243-257),
 // 8 bytes so that a wave scans 64 of them with one coalesced 512-B load. Culled / non-finite: sx > ex.
@@ -36,6 +37,16 @@ struct __attribute__((aligned(16))) RasterRec {
 struct __attribute__((aligned(8))) ShadeDescG {
   int32_t shader, tw, th, _pad;
   const uint32_t *tex;
+};
+
+// One mesh instance of one frame for the device vertex stage
+struct DrawDesc {
+  const srz_vertex *verts;
+  const uint32_t *faces;
+  uint32_t n_faces;
+  uint32_t tri_off; // first output triangle (global index into tris[])
+  float zscale, zoffset;
+  float ndc_mvp[16], normal_m[16];
 };
 
 struct FrameDesc {
@@ -92,6 +103,7 @@ struct RenderArgs {
   unsigned long long *timeline; // diagnostic (STATS variant only): per tile {start, end (wall clock 100 MHz), hw_id, blocks}
 };
 
+void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, hipStream_t s);
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
 void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
                   uint32_t max_tris, hipStream_t s);

@@ -159,6 +159,45 @@ __device__ __forceinline__ bool cover_s(const TriXY &t, float fx, float fy, floa
 }
 
 // ================================================================================================================
+// k_vertex — the vertex stage, Scene::loadTriangleStream (src/Scene.cpp:927-958): one thread per face.
+//   pos' = to_vec3(NDC_MVP * (p,1)) ; pos'.z = pos'.z*scale + offset ; nrm' = to_vec3(Normal_M * (n,1)) ; uv copied
+// glm's operator*(mat4,vec4) order: (m0*v.x + m1*v.y) + (m2*v.z + m3*v.w); Tools::to_vec3 divides by w (src/Tools.cpp:74-76).
+// ================================================================================================================
+__device__ __forceinline__ void xform_div_w(const SRZ_CAS float *m, float x, float y, float z, float &ox, float &oy, float &oz) {
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float add0 = m[0 * 4 + i] * x + m[1 * 4 + i] * y;
+    const float add1 = m[2 * 4 + i] * z + m[3 * 4 + i]; // * 1.0f is exact
+    r[i] = add0 + add1;
+  }
+  ox = r[0] / r[3], oy = r[1] / r[3], oz = r[2] / r[3];
+}
+
+__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris) {
+  const SRZ_CAS DrawDesc *d = as_const(draws) + blockIdx.y;
+  const uint32_t n_faces = d->n_faces;
+  const SRZ_CAS srz_vertex *verts = as_const(d->verts);
+  const SRZ_CAS uint32_t *faces = as_const(d->faces);
+  const float zs = d->zscale, zo = d->zoffset;
+  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f < n_faces; f += gridDim.x * 256) {
+    srz_tri t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const SRZ_CAS srz_vertex *v = verts + faces[3 * f + k];
+      const float px = v->pos[0], py = v->pos[1], pz = v->pos[2], nx = v->nrm[0], ny = v->nrm[1], nz = v->nrm[2];
+      float x, y, z;
+      xform_div_w(d->ndc_mvp, px, py, pz, x, y, z);
+      t.pos[k][0] = x, t.pos[k][1] = y, t.pos[k][2] = z * zs + zo;
+      xform_div_w(d->normal_m, nx, ny, nz, x, y, z);
+      t.nrm[k][0] = x, t.nrm[k][1] = y, t.nrm[k][2] = z;
+      t.uv[k][0] = v->uv[0], t.uv[k][1] = v->uv[1];
+    }
+    tris[d->tri_off + f] = t;
+  }
+}
+
+// ================================================================================================================
 // k_setup — per triangle: finite check, bbox, backface test (src/Triangle.cpp:147-151,243-257; Rasterizer.cpp:203)
 // ================================================================================================================
 template <bool STATS>
@@ -1021,6 +1060,13 @@ __global__ void k_tex_convert(const uint8_t *bgr, int w, int h, int row_stride, 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
+void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, hipStream_t s) {
+  if (n_draws == 0 || max_faces == 0) return;
+  dim3 grid((max_faces + 255) / 256, n_draws);
+  if (grid.x > 1024) grid.x = 1024;
+  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris);
+}
+
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s) {
   if (n_frames <= 0 || max_tris == 0) return;
   dim3 grid((max_tris + 255) / 256, n_frames);

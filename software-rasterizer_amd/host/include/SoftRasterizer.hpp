@@ -174,6 +174,18 @@ public:
   std::vector<ObjTuple> loadTriangleStream();
   std::vector<light_struct> loadLights();
 
+  // What loadTriangleStream computes per mesh before touching a vertex (src/Scene.cpp:922-923) — handed to the device
+  // vertex stage instead of running the per-face loop on the host.
+  struct MeshDraw {
+    std::string name;
+    Object *mesh;
+    std::shared_ptr<Shader> shader;
+    glm::mat4 ndc_mvp, normal_m;
+  };
+  std::vector<MeshDraw> meshDraws();
+  float depthScale() const { return scale; }
+  float depthOffset() const { return offset; }
+
   const glm::mat4 &viewMatrix() const { return m_view; }
   const glm::mat4 &projectionMatrix() const { return m_projection; }
   const glm::mat4 &ndcMatrix() const { return m_ndcToScreenMatrix; }
@@ -246,11 +258,16 @@ public:
   };
   bool collect_stats = false;
   Stats last_stats;
+  // true (default): meshes live on the GPU and draw() runs the vertex stage there (srz_draw_scene);
+  // false: Scene::loadTriangleStream() on the host, then srz_draw (same result bit for bit)
+  bool device_vertex_stage = true;
 
 private:
   void init();
   srz_ctx *m_ctx = nullptr;
   std::unordered_map<const TextureLoader *, int> m_texSlots;
+  std::unordered_map<const Object *, std::pair<int, std::size_t>> m_meshSlots; // mesh → (slot, face count at upload)
+  int textureSlot(const std::shared_ptr<Shader> &sh);
   std::vector<std::weak_ptr<TextureLoader>> m_texOwners;
 };
 

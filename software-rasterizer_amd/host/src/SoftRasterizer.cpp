@@ -428,6 +428,21 @@ std::vector<Scene::ObjTuple> Scene::loadTriangleStream() {
   return stream;
 }
 
+std::vector<Scene::MeshDraw> Scene::meshDraws() {
+  std::vector<MeshDraw> out;
+  for (const std::string &name : m_objOrder) {
+    const ObjInfo &obj = m_loadedObjs[name];
+    if (!obj.mesh) continue;
+    const glm::mat4 &modelMatrix = obj.mesh->getModelMatrix();
+    MeshDraw d;
+    d.name = name, d.mesh = obj.mesh.get(), d.shader = obj.mesh->shader();
+    d.ndc_mvp = m_ndcToScreenMatrix * m_projection * m_view * modelMatrix;
+    d.normal_m = glm::transpose(glm::inverse(modelMatrix));
+    out.push_back(std::move(d));
+  }
+  return out;
+}
+
 // ---- RenderingPipeline (src/Render.cpp) ---------------------------------------------------------------------------
 RenderingPipeline::RenderingPipeline() : RenderingPipeline(800, 600) {}
 RenderingPipeline::RenderingPipeline(std::size_t width, std::size_t height) : m_width(width), m_height(height) {
@@ -487,6 +502,20 @@ void TraditionalRasterizer::init() {
 }
 TraditionalRasterizer::~TraditionalRasterizer() { srz_destroy(m_ctx); }
 
+int TraditionalRasterizer::textureSlot(const std::shared_ptr<Shader> &sh) {
+  TextureLoader *tl = sh->getTextureObject().get();
+  auto it = m_texSlots.find(tl);
+  if (it == m_texSlots.end()) {
+    int slot = (int)m_texSlots.size();
+    if (slot >= 64) throw std::runtime_error("draw: more than 64 distinct textures");
+    int rc = srz_texture_upload(m_ctx, slot, tl->bgr().data(), (int)tl->width(), (int)tl->height(), (int)tl->width() * 3);
+    if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+    it = m_texSlots.emplace(tl, slot).first;
+    m_texOwners.push_back(sh->getTextureObject()); // keep the key's identity stable
+  }
+  return it->second;
+}
+
 void TraditionalRasterizer::draw(Primitive type) {
   if ((type != Primitive::LINES) && (type != Primitive::TRIANGLES)) {
     log("error", "Primitive Type is not supported!");
@@ -498,6 +527,64 @@ void TraditionalRasterizer::draw(Primitive type) {
   m_justCleared = false;
   for (auto &kv : m_scenes) {
     Scene &scene = *kv.second;
+    if (device_vertex_stage) { // meshes resident on the GPU, vertex stage there (k_vertex)
+      std::vector<light_struct> lights = scene.loadLights();
+      const glm::vec3 eye = scene.loadEyeVec();
+      std::vector<srz_light> L(lights.size());
+      for (size_t i = 0; i < lights.size(); ++i) {
+        L[i].pos[0] = lights[i].position.x, L[i].pos[1] = lights[i].position.y, L[i].pos[2] = lights[i].position.z;
+        L[i].intensity[0] = lights[i].intensity.x, L[i].intensity[1] = lights[i].intensity.y, L[i].intensity[2] = lights[i].intensity.z;
+      }
+      std::vector<srz_mesh_draw> D;
+      for (Scene::MeshDraw &md : scene.meshDraws()) {
+        const auto &faces = md.mesh->getFaces();
+        if (faces.empty()) continue;
+        if (!md.shader) throw std::runtime_error("draw: a mesh with triangles has no shader bound (bindShader2Mesh)"); // D14
+        auto it = m_meshSlots.find(md.mesh);
+        if (it == m_meshSlots.end() || it->second.second != faces.size()) {
+          const int slot = it == m_meshSlots.end() ? (int)m_meshSlots.size() : it->second.first;
+          if (slot >= 256) throw std::runtime_error("draw: more than 256 meshes");
+          const auto &V = md.mesh->getVertices();
+          std::vector<srz_vertex> v(V.size());
+          for (size_t i = 0; i < V.size(); ++i) {
+            v[i].pos[0] = V[i].position.x, v[i].pos[1] = V[i].position.y, v[i].pos[2] = V[i].position.z;
+            v[i].nrm[0] = V[i].normal.x, v[i].nrm[1] = V[i].normal.y, v[i].nrm[2] = V[i].normal.z;
+            v[i].uv[0] = V[i].texCoord.x, v[i].uv[1] = V[i].texCoord.y;
+          }
+          std::vector<uint32_t> f(faces.size() * 3);
+          for (size_t i = 0; i < faces.size(); ++i) f[3 * i] = faces[i].x, f[3 * i + 1] = faces[i].y, f[3 * i + 2] = faces[i].z;
+          int rc = srz_mesh_upload(m_ctx, slot, v.data(), (uint32_t)v.size(), f.data(), (uint32_t)faces.size());
+          if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+          m_meshSlots[md.mesh] = {slot, faces.size()};
+          it = m_meshSlots.find(md.mesh);
+        }
+        srz_mesh_draw d{};
+        d.mesh_id = it->second.first, d.shader = (int)md.shader->type(), d.tex_id = -1;
+        const SHADERS_TYPE st = md.shader->type();
+        if (st == SHADERS_TYPE::TEXTURE || st == SHADERS_TYPE::DISPLACEMENT || st == SHADERS_TYPE::BUMP) d.tex_id = textureSlot(md.shader);
+        std::memcpy(d.ndc_mvp, md.ndc_mvp.data(), 64), std::memcpy(d.normal_m, md.normal_m.data(), 64);
+        D.push_back(d);
+      }
+      srz_scene_frame sf{};
+      sf.width = (int)m_width, sf.height = (int)m_height;
+      sf.eye[0] = eye.x, sf.eye[1] = eye.y, sf.eye[2] = eye.z;
+      sf.ka[0] = Shader::ka.x, sf.ka[1] = Shader::ka.y, sf.ka[2] = Shader::ka.z;
+      sf.ks[0] = Shader::ks.x, sf.ks[1] = Shader::ks.y, sf.ks[2] = Shader::ks.z;
+      sf.p = Shader::p, sf.kh = Shader::kh, sf.kn = Shader::kn;
+      sf.zscale = scene.depthScale(), sf.zoffset = scene.depthOffset();
+      sf.n_lights = (uint32_t)L.size(), sf.lights = L.data();
+      sf.n_draws = (uint32_t)D.size(), sf.draws = D.data();
+      sf.flags = SRZ_EXACT_SPLIT | (fused ? SRZ_FUSED_CLEAR : 0u);
+      fused = false;
+      srz_stats st{};
+      int rc = srz_draw_scene(m_ctx, prim, &sf, m_zBuffer.data(), m_channels[0].data(), m_channels[1].data(), m_channels[2].data(),
+                              collect_stats ? &st : nullptr);
+      if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+      last_stats.n_tris += st.n_tris, last_stats.n_culled += st.n_culled, last_stats.pixel_tests += st.pixel_tests;
+      last_stats.fragments += st.fragments, last_stats.shaded += st.shaded, last_stats.visible += st.visible;
+      last_stats.visible_textured += st.visible_textured;
+      continue;
+    }
     std::vector<Scene::ObjTuple> stream = scene.loadTriangleStream();
     std::vector<light_struct> lights = scene.loadLights();
     const glm::vec3 eye = scene.loadEyeVec();
@@ -519,19 +606,7 @@ void TraditionalRasterizer::draw(Primitive type) {
       b.n_tris = (uint32_t)tris.size();
       b.tris = reinterpret_cast<const srz_tri *>(tris.data());
       const bool needs_tex = sh->type() == SHADERS_TYPE::TEXTURE || sh->type() == SHADERS_TYPE::DISPLACEMENT || sh->type() == SHADERS_TYPE::BUMP;
-      if (needs_tex) {
-        TextureLoader *tl = sh->getTextureObject().get();
-        auto it = m_texSlots.find(tl);
-        if (it == m_texSlots.end()) {
-          int slot = (int)m_texSlots.size();
-          if (slot >= 64) throw std::runtime_error("draw: more than 64 distinct textures");
-          int rc = srz_texture_upload(m_ctx, slot, tl->bgr().data(), (int)tl->width(), (int)tl->height(), (int)tl->width() * 3);
-          if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
-          it = m_texSlots.emplace(tl, slot).first;
-          m_texOwners.push_back(sh->getTextureObject()); // keep the key's identity stable
-        }
-        b.tex_id = it->second;
-      }
+      if (needs_tex) b.tex_id = textureSlot(sh);
       B.push_back(b);
     }
     srz_frame fr{};

@@ -1,5 +1,6 @@
 // capi.cpp — plain-C access to the C++ host layer (Scene building / vertex stage / asset loaders) for Python tools
 // (bench.py, tests).  This is host logic ABOVE the raster boundary: nothing here touches the GPU.  Handles are opaque.
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -117,6 +118,18 @@ int srzh_batch_copy(srzh_scene *s, int b, void *out_tris96) {
   if (b < 0 || b >= (int)s->stream.size()) return -1;
   const auto &t = std::get<1>(s->stream[b]);
   std::memcpy(out_tris96, t.data(), t.size() * sizeof(RasterTriangle));
+  return 0;
+}
+// per-mesh matrices of the vertex stage (what the device vertex stage consumes), in registration order
+int srzh_n_mesh_draws(srzh_scene *s) { return (int)s->scene->meshDraws().size(); }
+int srzh_mesh_draw(srzh_scene *s, int i, char *name64, int *shader, float *ndc_mvp16, float *normal16, float *zscale_offset2) {
+  auto d = s->scene->meshDraws();
+  if (i < 0 || i >= (int)d.size()) return -1;
+  std::snprintf(name64, 64, "%s", d[i].name.c_str());
+  *shader = d[i].shader ? (int)d[i].shader->type() : -1;
+  std::memcpy(ndc_mvp16, d[i].ndc_mvp.data(), 64);
+  std::memcpy(normal16, d[i].normal_m.data(), 64);
+  zscale_offset2[0] = s->scene->depthScale(), zscale_offset2[1] = s->scene->depthOffset();
   return 0;
 }
 int srzh_n_lights(srzh_scene *s) { return (int)s->scene->loadLights().size(); }

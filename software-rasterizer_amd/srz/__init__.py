@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libsrz.so")
 _lib = None
 
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
-           "srz_draw", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
+           "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
            "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath"]
 
@@ -44,6 +44,9 @@ def lib():
         L.srz_texture_upload.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
         L.srz_draw.argtypes = [vp, C.c_int, C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
         L.srz_frameset_create.argtypes = [vp, C.POINTER(abi.SrzFrame), C.c_int, C.POINTER(vp)]
+        L.srz_sceneset_create.argtypes = [vp, C.POINTER(abi.SrzSceneFrame), C.c_int, C.POINTER(vp)]
+        L.srz_mesh_upload.argtypes = [vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32]
+        L.srz_draw_scene.argtypes = [vp, C.c_int, C.POINTER(abi.SrzSceneFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
         L.srz_frameset_destroy.argtypes = [vp, vp]
         L.srz_frameset_destroy.restype = None
         L.srz_frameset_local_rows.argtypes = [vp, vp]
@@ -73,8 +76,12 @@ class FrameSet:
     def __init__(self, ctx, frames):
         self.ctx, self.frames = ctx, list(frames)
         self.h = C.c_void_p()
-        arr = abi.frames_array(self.frames)
-        ctx._check(lib().srz_frameset_create(ctx.h, arr, len(self.frames), C.byref(self.h)))
+        if isinstance(self.frames[0], abi.SceneFrame):  # meshes + matrices: vertex stage runs on the device
+            arr = abi.scene_frames_array(self.frames)
+            ctx._check(lib().srz_sceneset_create(ctx.h, arr, len(self.frames), C.byref(self.h)))
+        else:
+            arr = abi.frames_array(self.frames)
+            ctx._check(lib().srz_frameset_create(ctx.h, arr, len(self.frames), C.byref(self.h)))
         self.n_frames = len(self.frames)
         self.width, self.height = self.frames[0].width, self.frames[0].height
         self.local_rows = lib().srz_frameset_local_rows(ctx.h, self.h)
@@ -133,6 +140,12 @@ class Context:
         assert c == 3
         self._check(lib().srz_texture_upload(self.h, tex_id, a.ctypes.data, w, h, w * 3))
 
+    def mesh_upload(self, mesh_id, verts8, faces):
+        """verts8: (nV,8) float32 [pos3 nrm3 uv2]; faces: (nF,3) uint32."""
+        v = np.ascontiguousarray(verts8, dtype=np.float32)
+        f = np.ascontiguousarray(faces, dtype=np.uint32)
+        self._check(lib().srz_mesh_upload(self.h, mesh_id, v.ctypes.data, len(v), f.ctypes.data, len(f)))
+
     def draw(self, frame, planes=None, primitive=abi.PRIMITIVE_TRIANGLES, want_stats=False):
         """TraditionalRasterizer::draw for one scene; planes (z,c0,c1,c2) are modified in place."""
         if planes is None:
@@ -141,8 +154,9 @@ class Context:
                       np.zeros((h, w), np.float32))
         z, c0, c1, c2 = planes
         st = abi.SrzStats()
-        self._check(lib().srz_draw(self.h, primitive, C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2),
-                                   C.byref(st) if want_stats else None))
+        fn = lib().srz_draw_scene if isinstance(frame, abi.SceneFrame) else lib().srz_draw
+        self._check(fn(self.h, primitive, C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2),
+                       C.byref(st) if want_stats else None))
         return planes, (st.as_dict() if want_stats else None)
 
     def frameset(self, frames):

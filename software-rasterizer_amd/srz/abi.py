@@ -16,7 +16,8 @@ EXACT_SPLIT, UNIFIED, FUSED_CLEAR = 0, 1, 2
 # numpy view of srz_tri (96 B): pos[3][3], nrm[3][3], uv[3][2]
 TRI_DTYPE = np.dtype([("pos", "<f4", (3, 3)), ("nrm", "<f4", (3, 3)), ("uv", "<f4", (3, 2))])
 LIGHT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("intensity", "<f4", (3,))])
-assert TRI_DTYPE.itemsize == 96 and LIGHT_DTYPE.itemsize == 24
+VERTEX_DTYPE = np.dtype([("pos", "<f4", (3,)), ("nrm", "<f4", (3,)), ("uv", "<f4", (2,))])
+assert TRI_DTYPE.itemsize == 96 and LIGHT_DTYPE.itemsize == 24 and VERTEX_DTYPE.itemsize == 32
 
 
 class SrzBatch(C.Structure):
@@ -29,6 +30,18 @@ class SrzFrame(C.Structure):
                 ("ks", C.c_float * 3), ("p", C.c_float), ("kh", C.c_float), ("kn", C.c_float),
                 ("n_lights", C.c_uint32), ("n_batches", C.c_uint32), ("lights", C.c_void_p),
                 ("batches", C.c_void_p), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class SrzMeshDraw(C.Structure):
+    _fields_ = [("mesh_id", C.c_int32), ("shader", C.c_int32), ("tex_id", C.c_int32), ("_pad", C.c_int32),
+                ("ndc_mvp", C.c_float * 16), ("normal_m", C.c_float * 16)]
+
+
+class SrzSceneFrame(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("eye", C.c_float * 3), ("ka", C.c_float * 3),
+                ("ks", C.c_float * 3), ("p", C.c_float), ("kh", C.c_float), ("kn", C.c_float),
+                ("zscale", C.c_float), ("zoffset", C.c_float), ("n_lights", C.c_uint32), ("n_draws", C.c_uint32),
+                ("lights", C.c_void_p), ("draws", C.c_void_p), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class SrzStats(C.Structure):
@@ -89,6 +102,48 @@ class Frame:
     def with_flags(self, flags):
         self.c.flags = int(flags)
         return self
+
+
+class SceneFrame:
+    """Python-side owner of one srz_scene_frame (meshes by slot + the vertex-stage matrices)."""
+
+    def __init__(self, width, height, eye, lights, draws, zscale, zoffset, flags=0, ka=DEFAULT_KA, ks=DEFAULT_KS,
+                 p=DEFAULT_P, kh=DEFAULT_KH, kn=DEFAULT_KN):
+        """draws: list of (mesh_id, shader, tex_id, ndc_mvp[16], normal_m[16])."""
+        self.lights = np.ascontiguousarray(np.asarray(lights, dtype=np.float32).reshape(-1, 6)).view(LIGHT_DTYPE).reshape(-1)
+        self._draws = (SrzMeshDraw * max(1, len(draws)))()
+        for i, (mesh_id, shader, tex_id, mvp, nm) in enumerate(draws):
+            d = self._draws[i]
+            d.mesh_id, d.shader, d.tex_id = int(mesh_id), int(shader), int(tex_id)
+            d.ndc_mvp[:] = [float(x) for x in np.asarray(mvp, np.float32).reshape(16)]
+            d.normal_m[:] = [float(x) for x in np.asarray(nm, np.float32).reshape(16)]
+        f = SrzSceneFrame()
+        f.width, f.height = int(width), int(height)
+        f.eye[:] = [float(x) for x in eye]
+        f.ka[:] = [float(x) for x in ka]
+        f.ks[:] = [float(x) for x in ks]
+        f.p, f.kh, f.kn = float(p), float(kh), float(kn)
+        f.zscale, f.zoffset = float(zscale), float(zoffset)
+        f.n_lights, f.n_draws = len(self.lights), len(draws)
+        f.lights = self.lights.ctypes.data if len(self.lights) else None
+        f.draws = C.cast(self._draws, C.c_void_p).value
+        f.flags = int(flags)
+        self.c = f
+
+    @property
+    def width(self):
+        return self.c.width
+
+    @property
+    def height(self):
+        return self.c.height
+
+
+def scene_frames_array(frames):
+    arr = (SrzSceneFrame * len(frames))()
+    for i, f in enumerate(frames):
+        arr[i] = f.c
+    return arr
 
 
 def frames_array(frames):

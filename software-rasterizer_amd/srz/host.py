@@ -41,6 +41,8 @@ def lib():
         L.srzh_batch_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(vp),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.srzh_batch_copy.argtypes = [vp, C.c_int, vp]
+        L.srzh_n_mesh_draws.argtypes = [vp]
+        L.srzh_mesh_draw.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_int), fp, fp, fp]
         L.srzh_n_lights.argtypes = [vp]
         L.srzh_lights_copy.argtypes = [vp, fp]
         L.srzh_set_reference_exact_lights.argtypes = [vp, C.c_int]
@@ -119,6 +121,19 @@ class Scene:
         f = np.empty((nf.value, 3), np.uint32)
         lib().srzh_mesh_copy(self.h, name.encode(), v.ctypes.data_as(C.POINTER(C.c_float)), f.ctypes.data)
         return v, f
+
+    def mesh_draws(self):
+        """[(mesh_name, shader_type, ndc_mvp[16], normal_m[16])] in registration order, plus (zscale, zoffset)."""
+        out, zz = [], np.zeros(2, np.float32)
+        fp = C.POINTER(C.c_float)
+        for i in range(lib().srzh_n_mesh_draws(self.h)):
+            name = C.create_string_buffer(64)
+            sh = C.c_int()
+            mvp, nm = np.empty(16, np.float32), np.empty(16, np.float32)
+            self._chk(lib().srzh_mesh_draw(self.h, i, name, C.byref(sh), mvp.ctypes.data_as(fp), nm.ctypes.data_as(fp),
+                                           zz.ctypes.data_as(fp)), "meshDraws")
+            out.append((name.value.decode(), sh.value, mvp, nm))
+        return out, (float(zz[0]), float(zz[1]))
 
     def lights(self):
         n = lib().srzh_n_lights(self.h)

@@ -65,6 +65,31 @@ class Workload:
         ka, ks, p, kh, kn = host.shader_constants()
         return abi.Frame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), batches, flags, ka, ks, p, kh, kn)
 
+    def upload_meshes(self, ctx):
+        """Meshes resident on the GPU for the device vertex stage: slot i = i-th registered mesh."""
+        for i, (mname, _, _, _, _) in enumerate(self.meshes):
+            v, f = self.scene.mesh(mname)
+            ctx.mesh_upload(i, v, f)
+
+    def scene_frame(self, frame_idx, flags=abi.FUSED_CLEAR):
+        """Same frame as frame(i) but as meshes + vertex-stage matrices (the vertex stage then runs on the device)."""
+        deg = float((10 * frame_idx) % 360)
+        sc = self.scene
+        for (mname, _, _, t, s) in self.meshes:
+            sc.set_model(mname, Y, deg, t, (s, s, s))
+        sc.set_view(EYE, (0, 0, 0), Y)
+        sc.set_projection(45.0, 0.1, 100.0)
+        if not self.texture_arrays:
+            self.frame(frame_idx)  # registers the texture slots
+        draws, (zs, zo) = sc.mesh_draws()
+        slot = {m[0]: i for i, m in enumerate(self.meshes)}
+        d = []
+        for (name, shader, mvp, nm) in draws:
+            needs = shader in (abi.SHADER_TEXTURE, abi.SHADER_DISPLACEMENT, abi.SHADER_BUMP)
+            d.append((slot[name], shader, 0 if needs else -1, mvp, nm))
+        ka, ks, p, kh, kn = host.shader_constants()
+        return abi.SceneFrame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), d, zs, zo, flags, ka, ks, p, kh, kn)
+
     def upload_textures(self, ctx):
         for slot, tex in enumerate(self.texture_arrays):
             ctx.texture_upload(slot, tex)
