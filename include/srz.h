@@ -187,6 +187,27 @@ int srz_frameset_local_rows(const srz_ctx *ctx, const srz_frameset *fs);
 size_t srz_frameset_out_bytes(const srz_ctx *ctx, const srz_frameset *fs);
 int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_bytes,
                         uint32_t flags, void *stream);
+/* display()'s resolve on the device (cv::merge + convertTo(CV_8UC3), src/Render.cpp:61-62): the three colour planes of
+ * a rendered buffer (layout of srz_frameset_render) → interleaved 8-bit [frame][local_rows][width][3], round half to even,
+ * saturate.  Asynchronous on `stream`.  width must be a multiple of 4. */
+int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_planes, void *d_bgr8, size_t bgr8_bytes,
+                          void *stream);
+/* Re-upload the per-frame data of a sceneset (matrices, eye, lights, shader constants, flags, shader/texture per draw)
+ * without re-allocating anything.  The structure must be unchanged: same frame count and size, same mesh slots and face
+ * counts per draw, same light counts; otherwise SRZ_E_INVALID (create a new set). */
+int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *frames, int n_frames);
+
+/* ---- device-resident framebuffer = RenderingPipeline's m_zBuffer + m_channels kept in HBM between calls ----------
+ * clear(Color|Depth) immediately followed by a draw costs nothing (fused into the raster kernel); planes come back to
+ * the host only when asked for, and display() only needs the 3-byte resolved image. */
+typedef struct srz_target srz_target;
+int srz_target_create(srz_ctx *ctx, int width, int height, srz_target **out); /* starts cleared (z=+inf, colour 0) */
+void srz_target_destroy(srz_ctx *ctx, srz_target *t);
+int srz_target_clear(srz_ctx *ctx, srz_target *t, int color, int depth);      /* = RenderingPipeline::clear(Buffers) */
+/* draw frame 0 of a 1-frame set (srz_frameset_create / srz_sceneset_create of the target's size) into the target */
+int srz_target_draw(srz_ctx *ctx, srz_target *t, int primitive, srz_frameset *fs, srz_stats *stats);
+int srz_target_read(srz_ctx *ctx, srz_target *t, float *z, float *c0, float *c1, float *c2); /* NULL planes are skipped */
+int srz_target_read_bgr8(srz_ctx *ctx, srz_target *t, uint8_t *bgr8);         /* display()'s resolve, W*H*3 bytes */
 /* synchronous: runs the counting variant of the kernels once and returns the counters */
 int srz_frameset_stats(srz_ctx *ctx, srz_frameset *fs, srz_stats *stats);
 /* Algorithmic bytes of one render of the frameset on this ctx (SURVEY §8d / DESIGN.md):

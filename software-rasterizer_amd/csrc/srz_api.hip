@@ -1,6 +1,7 @@
 // srz_api.hip — the C ABI declared in include/srz.h (host side: contexts, framesets, uploads, launches).
 // No CPU fallback exists: without a usable gfx950 device every compute entry point returns SRZ_E_NODEVICE.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,13 @@ struct srz_ctx {
   size_t timeline_cap = 0;
 };
 
+struct srz_target {
+  int width = 0, height = 0;
+  float *d_planes = nullptr; // [z,c0,c1,c2][H][W]
+  uint8_t *d_bgr8 = nullptr;
+  bool pending_clear = false; // clear(Color|Depth) not yet materialised: the next draw runs with SRZ_FUSED_CLEAR
+};
+
 struct srz_frameset {
   int n_frames = 0, width = 0, height = 0;
   int shard_rank = 0, shard_world = 1;
@@ -63,6 +71,8 @@ struct srz_frameset {
   uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
+  std::vector<DrawDesc> h_draws;
+  std::vector<int> h_draw_mesh;
   uint32_t n_draws = 0, max_faces = 0;
   uint64_t sdesc_version = 0;
   uint32_t tiles_x = 0, max_tiles = 0;
@@ -497,11 +507,13 @@ int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frame
       dd.zscale = frames[f].zscale, dd.zoffset = frames[f].zoffset;
       std::memcpy(dd.ndc_mvp, dr.ndc_mvp, sizeof dd.ndc_mvp), std::memcpy(dd.normal_m, dr.normal_m, sizeof dd.normal_m);
       h.push_back(dd);
+      fs->h_draw_mesh.push_back(dr.mesh_id);
       first += m.n_faces;
       fs->max_faces = std::max(fs->max_faces, m.n_faces);
     }
   }
   fs->n_draws = (uint32_t)h.size();
+  fs->h_draws = h;
   hipError_t e = hipMalloc(&fs->d_draws, sizeof(DrawDesc) * std::max<size_t>(h.size(), 1));
   if (e == hipSuccess && !h.empty()) e = hipMemcpy(fs->d_draws, h.data(), sizeof(DrawDesc) * h.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -509,6 +521,152 @@ int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frame
     return fail(ctx, SRZ_E_NOMEM, std::string("srz_sceneset_create: ") + hipGetErrorString(e));
   }
   *out = fs;
+  return SRZ_OK;
+}
+
+int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *frames, int n_frames) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!fs || !frames || !fs->d_draws) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_update: not a sceneset");
+  if (n_frames != fs->n_frames) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_update: frame count changed");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<srz_light> h_lights((size_t)fs->total_lights);
+  size_t di = 0, bi = 0;
+  bool batches_changed = false;
+  for (int f = 0; f < n_frames; ++f) {
+    const srz_scene_frame &sf = frames[f];
+    FrameDesc &d = fs->h_frames[f];
+    if (sf.width != fs->width || sf.height != fs->height || sf.n_lights != d.n_lights || sf.n_draws != d.n_batches ||
+        (sf.n_lights && !sf.lights) || (sf.n_draws && !sf.draws))
+      return fail(ctx, SRZ_E_INVALID, "srz_sceneset_update: structure changed");
+    std::memcpy(d.eye, sf.eye, sizeof d.eye), std::memcpy(d.ka, sf.ka, sizeof d.ka), std::memcpy(d.ks, sf.ks, sizeof d.ks);
+    d.p = sf.p, d.kh = sf.kh, d.kn = sf.kn, d.flags = sf.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR);
+    if (sf.n_lights) std::memcpy(&h_lights[d.light_off], sf.lights, sizeof(srz_light) * sf.n_lights);
+    for (uint32_t k = 0; k < sf.n_draws; ++k, ++di, ++bi) {
+      const srz_mesh_draw &dr = sf.draws[k];
+      if (dr.mesh_id != fs->h_draw_mesh[di] || dr.mesh_id < 0 || dr.mesh_id >= MAX_MESH ||
+          ctx->mesh[dr.mesh_id].n_faces != fs->h_draws[di].n_faces || ctx->mesh[dr.mesh_id].d_verts != fs->h_draws[di].verts)
+        return fail(ctx, SRZ_E_INVALID, "srz_sceneset_update: mesh binding changed");
+      if (dr.shader < SRZ_SHADER_NORMAL || dr.shader > SRZ_SHADER_BUMP) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_update: unknown shader type");
+      DrawDesc &dd = fs->h_draws[di];
+      dd.zscale = sf.zscale, dd.zoffset = sf.zoffset;
+      std::memcpy(dd.ndc_mvp, dr.ndc_mvp, sizeof dd.ndc_mvp), std::memcpy(dd.normal_m, dr.normal_m, sizeof dd.normal_m);
+      BatchDesc &b = fs->h_batches[bi];
+      if (b.shader != dr.shader || b.tex_id != dr.tex_id) b.shader = dr.shader, b.tex_id = dr.tex_id, batches_changed = true;
+    }
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // descriptors may still be read by a render in flight
+  HIP_TRY(ctx, hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
+  if (!fs->h_draws.empty()) HIP_TRY(ctx, hipMemcpy(fs->d_draws, fs->h_draws.data(), sizeof(DrawDesc) * fs->h_draws.size(), hipMemcpyHostToDevice));
+  if (!h_lights.empty()) HIP_TRY(ctx, hipMemcpy(fs->d_lights, h_lights.data(), sizeof(srz_light) * h_lights.size(), hipMemcpyHostToDevice));
+  if (batches_changed) {
+    HIP_TRY(ctx, hipMemcpy(fs->d_batches, fs->h_batches.data(), sizeof(BatchDesc) * fs->h_batches.size(), hipMemcpyHostToDevice));
+    fs->sdesc_version = 0; // re-resolve batch → shader / texture at the next render
+  }
+  fs->have_stats = false;
+  return SRZ_OK;
+}
+
+int srz_target_create(srz_ctx *ctx, int width, int height, srz_target **out) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!out || width <= 0 || height <= 0 || width > 32767 || height > 32767) return fail(ctx, SRZ_E_INVALID, "srz_target_create: bad size");
+  *out = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  srz_target *t = new (std::nothrow) srz_target();
+  if (!t) return fail(ctx, SRZ_E_NOMEM, "srz_target_create: out of host memory");
+  t->width = width, t->height = height;
+  const size_t plane = (size_t)width * height;
+  hipError_t e = hipMalloc(&t->d_planes, plane * 16);
+  if (e == hipSuccess) e = hipMalloc(&t->d_bgr8, plane * 3 + 16);
+  if (e != hipSuccess) {
+    (void)hipFree(t->d_planes), (void)hipFree(t->d_bgr8);
+    delete t;
+    return fail(ctx, SRZ_E_NOMEM, "srz_target_create: hipMalloc failed");
+  }
+  *out = t;
+  return srz_target_clear(ctx, t, 1, 1);
+}
+
+void srz_target_destroy(srz_ctx *ctx, srz_target *t) {
+  if (!t) return;
+  if (ctx) (void)hipSetDevice(ctx->device), (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(t->d_planes), (void)hipFree(t->d_bgr8);
+  delete t;
+}
+
+static int target_materialize_clear(srz_ctx *ctx, srz_target *t) {
+  if (!t->pending_clear) return SRZ_OK;
+  const size_t plane = (size_t)t->width * t->height;
+  HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)t->d_planes, 0x7f800000, plane, ctx->stream)); // +inf
+  HIP_TRY(ctx, hipMemsetAsync(t->d_planes + plane, 0, plane * 12, ctx->stream));
+  t->pending_clear = false;
+  return SRZ_OK;
+}
+
+int srz_target_clear(srz_ctx *ctx, srz_target *t, int color, int depth) {
+  if (!ctx || !t) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t plane = (size_t)t->width * t->height;
+  if (color && depth) {
+    t->pending_clear = true; // free if a draw follows; materialised by the next read / partial clear otherwise
+    return SRZ_OK;
+  }
+  if (!color && !depth) return SRZ_OK;
+  int rc = target_materialize_clear(ctx, t);
+  if (rc) return rc;
+  if (depth) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)t->d_planes, 0x7f800000, plane, ctx->stream));
+  if (color) HIP_TRY(ctx, hipMemsetAsync(t->d_planes + plane, 0, plane * 12, ctx->stream));
+  return SRZ_OK;
+}
+
+int srz_target_draw(srz_ctx *ctx, srz_target *t, int primitive, srz_frameset *fs, srz_stats *stats) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (primitive != SRZ_PRIMITIVE_LINES && primitive != SRZ_PRIMITIVE_TRIANGLES)
+    return fail(ctx, SRZ_E_PRIMITIVE, "Primitive Type is not supported!");
+  if (!t || !fs) return fail(ctx, SRZ_E_INVALID, "srz_target_draw: null argument");
+  if (fs->n_frames != 1 || fs->width != t->width || fs->height != t->height || fs->shard_world != 1)
+    return fail(ctx, SRZ_E_INVALID, "srz_target_draw: needs an unsharded 1-frame set of the target's size");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t flags = t->pending_clear ? SRZ_FUSED_CLEAR : 0u;
+  t->pending_clear = false;
+  int rc = render_impl(ctx, fs, t->d_planes, flags, ctx->stream, stats != nullptr);
+  if (rc == SRZ_OK && stats) rc = read_stats(ctx, ctx->stream, stats);
+  return rc;
+}
+
+int srz_target_read(srz_ctx *ctx, srz_target *t, float *z, float *c0, float *c1, float *c2) {
+  if (!ctx || !t) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = target_materialize_clear(ctx, t);
+  if (rc) return rc;
+  const size_t plane = (size_t)t->width * t->height;
+  float *host[4] = {z, c0, c1, c2};
+  for (int p = 0; p < 4; ++p)
+    if (host[p]) HIP_TRY(ctx, hipMemcpyAsync(host[p], t->d_planes + p * plane, plane * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SRZ_OK;
+}
+
+int srz_target_read_bgr8(srz_ctx *ctx, srz_target *t, uint8_t *bgr8) {
+  if (!ctx || !t || !bgr8) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = target_materialize_clear(ctx, t);
+  if (rc) return rc;
+  const size_t plane = (size_t)t->width * t->height;
+  if (t->width & 3) { // odd widths: resolve on the host from the planes (rare; keeps the kernel's 4-pixel contract)
+    std::vector<float> c(plane * 3);
+    HIP_TRY(ctx, hipMemcpyAsync(c.data(), t->d_planes + plane, plane * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < plane; ++i)
+      for (int k = 0; k < 3; ++k) {
+        float v = c[k * plane + i];
+        float r = (v == v) ? std::nearbyintf(v) : 0.0f;
+        bgr8[i * 3 + k] = (uint8_t)(r <= 0.0f ? 0 : (r >= 255.0f ? 255 : (int)r));
+      }
+    return SRZ_OK;
+  }
+  launch_resolve8(t->d_planes, t->d_bgr8, 1, (uint32_t)t->height, (uint32_t)t->width, 4ull * plane, ctx->stream);
+  HIP_TRY(ctx, hipMemcpyAsync(bgr8, t->d_bgr8, plane * 3, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SRZ_OK;
 }
 
@@ -539,6 +697,20 @@ int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_
   static const bool dbg = getenv("SRZ_DEBUG_FLAGS") != nullptr;
   flags &= (SRZ_UNIFIED | SRZ_FUSED_CLEAR) | (dbg ? 0xff00u : 0u);
   return render_impl(ctx, fs, (float *)d_out, flags, s, false);
+}
+
+int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_planes, void *d_bgr8, size_t bgr8_bytes, void *stream) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!fs || !d_planes || !d_bgr8) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: null argument");
+  if (fs->width & 3) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: width must be a multiple of 4");
+  if (bgr8_bytes < (size_t)fs->n_frames * fs->local_rows * (size_t)fs->width * 3) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: output too small");
+  if (((uintptr_t)d_planes & 15u) || ((uintptr_t)d_bgr8 & 3u)) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: misaligned buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  launch_resolve8((const float *)d_planes, (uint8_t *)d_bgr8, (uint32_t)fs->n_frames, fs->local_rows, (uint32_t)fs->width,
+                  4ull * fs->local_rows * (uint64_t)fs->width, s);
+  HIP_TRY(ctx, hipGetLastError());
+  return SRZ_OK;
 }
 
 int srz_frameset_stats(srz_ctx *ctx, srz_frameset *fs, srz_stats *stats) {

@@ -25,6 +25,7 @@
 // and rounded once.  The z-buffer is therefore expected to be bit-identical to the oracle's.
 #include "srz_device.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1025,6 +1026,43 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
       if (n_vis_tex) atomicAdd(&a.stats[ST_VISIBLE_TEX], n_vis_tex);
     }
   }
+}
+
+// ================================================================================================================
+// k_resolve8 — display()'s resolve (src/Render.cpp:61-62): cv::merge(planes 0,1,2) + convertTo(CV_8UC3) =
+// saturate_cast<uchar>(cvRound(v)): round half to even, clamp to [0,255]; NaN → 0.  4 pixels per thread: three 16-byte
+// plane reads → 12 output bytes (three dword stores).
+// ================================================================================================================
+__device__ __forceinline__ uint32_t to_u8(float v) {
+  if (!(v == v)) return 0u;
+  const float r = __builtin_rintf(v); // round half to even (default rounding mode)
+  return r <= 0.0f ? 0u : (r >= 255.0f ? 255u : (uint32_t)r);
+}
+__global__ __launch_bounds__(256) void k_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W,
+                                                  uint64_t frame_stride) {
+  const uint64_t quads_per_frame = (uint64_t)rows * W / 4; // W % 4 == 0 is required by the launcher
+  const uint64_t total = quads_per_frame * n_frames;
+  for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t f = q / quads_per_frame, i = (q - f * quads_per_frame) * 4;
+    const float *p = planes + f * frame_stride + (uint64_t)rows * W; // plane 1 = c0 (plane 0 is z)
+    const SRZ_CAS f32x4 *c0 = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(p + i));
+    const SRZ_CAS f32x4 *c1 = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(p + (uint64_t)rows * W + i));
+    const SRZ_CAS f32x4 *c2 = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(p + 2ull * rows * W + i));
+    const f32x4 a = *c0, b = *c1, c = *c2;
+    const uint32_t b0 = to_u8(a.x), g0 = to_u8(b.x), r0 = to_u8(c.x), b1 = to_u8(a.y), g1 = to_u8(b.y), r1 = to_u8(c.y);
+    const uint32_t b2 = to_u8(a.z), g2 = to_u8(b.z), r2 = to_u8(c.z), b3 = to_u8(a.w), g3 = to_u8(b.w), r3 = to_u8(c.w);
+    uint32_t *o = reinterpret_cast<uint32_t *>(out + (f * (uint64_t)rows * W + i) * 3);
+    o[0] = b0 | (g0 << 8) | (r0 << 16) | (b1 << 24);
+    o[1] = g1 | (r1 << 8) | (b2 << 16) | (g2 << 24);
+    o[2] = r2 | (b3 << 8) | (g3 << 16) | (r3 << 24);
+  }
+}
+void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
+                     hipStream_t s) {
+  const uint64_t total = (uint64_t)n_frames * rows * W / 4;
+  if (!total) return;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_resolve8, dim3(grid), dim3(256), 0, s, planes, out, n_frames, rows, W, frame_stride);
 }
 
 // Exhaustive check of the short exact sequences above against the IEEE expansions: all 2^32 bit patterns.

@@ -25,6 +25,8 @@
 #include "glm_min.hpp"
 
 struct srz_ctx;
+struct srz_target;
+struct srz_frameset;
 
 namespace SoftRasterizer {
 
@@ -228,8 +230,9 @@ public:
 
   std::size_t width() const { return m_width; }
   std::size_t height() const { return m_height; }
-  const std::vector<float> &zBuffer() const { return m_zBuffer; }
-  const std::vector<float> &channel(int i) const { return m_channels[i]; } // planar, 0..255 float, plane 0 = texture blue
+  // The framebuffer lives in HBM (srz_target); these accessors bring the planes to the host when they are stale.
+  const std::vector<float> &zBuffer() { syncToHost(); return m_zBuffer; }
+  const std::vector<float> &channel(int i) { syncToHost(); return m_channels[i]; } // planar, 0..255 float, plane 0 = texture blue
   const std::vector<uint8_t> &frameBuffer8() const { return m_frameBuffer8; } // interleaved 3 x u8 after display()
 
   virtual void draw(Primitive type) = 0; // protected in the reference; public here so harnesses can time draw() alone
@@ -243,6 +246,10 @@ protected:
   std::vector<float> m_zBuffer;
   std::vector<uint8_t> m_frameBuffer8;
   bool m_justCleared = false; // clear(Color|Depth) immediately before draw() → the fused-clear kernel path
+  void syncToHost();          // device planes → m_zBuffer / m_channels (no-op when they are current or there is no device)
+  srz_ctx *m_ctx = nullptr;       // set by TraditionalRasterizer; a pipeline without it keeps its planes on the host
+  srz_target *m_target = nullptr; // device-resident z + colour planes
+  bool m_hostStale = false;
 };
 
 // ---- include/render/Rasterizer.hpp ------------------------------------------------------------------------------
@@ -264,7 +271,7 @@ public:
 
 private:
   void init();
-  srz_ctx *m_ctx = nullptr;
+  std::unordered_map<const Scene *, srz_frameset *> m_sceneSets; // cached 1-frame scenesets (device vertex stage)
   std::unordered_map<const TextureLoader *, int> m_texSlots;
   std::unordered_map<const Object *, std::pair<int, std::size_t>> m_meshSlots; // mesh → (slot, face count at upload)
   int textureSlot(const std::shared_ptr<Shader> &sh);

@@ -458,9 +458,20 @@ void RenderingPipeline::clearFrameBuffer() {
 void RenderingPipeline::clearZDepth() { std::fill(m_zBuffer.begin(), m_zBuffer.end(), std::numeric_limits<float>::infinity()); }
 void RenderingPipeline::clear(Buffers flags) {
   const bool c = (flags & Buffers::Color) == Buffers::Color, d = (flags & Buffers::Depth) == Buffers::Depth;
+  if (m_target) { // planes are in HBM: clear there (free when a draw follows immediately)
+    if (srz_target_clear(m_ctx, m_target, c ? 1 : 0, d ? 1 : 0) != SRZ_OK) throw std::runtime_error(std::string("clear: ") + srz_last_error(m_ctx));
+    m_hostStale = m_hostStale || c || d;
+    return;
+  }
   if (c) clearFrameBuffer();
   if (d) clearZDepth();
   m_justCleared = c && d;
+}
+void RenderingPipeline::syncToHost() {
+  if (!m_target || !m_hostStale) return;
+  if (srz_target_read(m_ctx, m_target, m_zBuffer.data(), m_channels[0].data(), m_channels[1].data(), m_channels[2].data()) != SRZ_OK)
+    throw std::runtime_error(std::string("framebuffer read-back: ") + srz_last_error(m_ctx));
+  m_hostStale = false;
 }
 bool RenderingPipeline::addScene(std::shared_ptr<Scene> scene, std::optional<std::string> name) {
   try {
@@ -482,6 +493,11 @@ bool RenderingPipeline::addScene(std::shared_ptr<Scene> scene, std::optional<std
 // (src/Render.cpp:57-64): draw, cv::merge, convertTo(CV_8UC3) = saturate_cast<uchar>(cvRound(v)); no imshow here
 void RenderingPipeline::display(Primitive type) {
   draw(type);
+  if (m_target) { // resolve on the device, 3 bytes per pixel come back
+    if (srz_target_read_bgr8(m_ctx, m_target, m_frameBuffer8.data()) != SRZ_OK)
+      throw std::runtime_error(std::string("display: ") + srz_last_error(m_ctx));
+    return;
+  }
   const size_t n = m_width * m_height;
   for (size_t i = 0; i < n; ++i)
     for (int c = 0; c < 3; ++c) {
@@ -499,8 +515,20 @@ void TraditionalRasterizer::init() {
   if (const char *e = std::getenv("SRZ_DEVICE")) dev = std::atoi(e);
   int rc = srz_create(&m_ctx, dev);
   if (rc != SRZ_OK) throw std::runtime_error(std::string("TraditionalRasterizer: ") + srz_last_error(nullptr));
+  rc = srz_target_create(m_ctx, (int)m_width, (int)m_height, &m_target);
+  if (rc != SRZ_OK) {
+    std::string msg = srz_last_error(m_ctx);
+    srz_destroy(m_ctx);
+    m_ctx = nullptr;
+    throw std::runtime_error("TraditionalRasterizer: " + msg);
+  }
+  m_hostStale = false; // the constructor's clear() already filled the host planes with the same values
 }
-TraditionalRasterizer::~TraditionalRasterizer() { srz_destroy(m_ctx); }
+TraditionalRasterizer::~TraditionalRasterizer() {
+  for (auto &kv : m_sceneSets) srz_frameset_destroy(m_ctx, kv.second);
+  srz_target_destroy(m_ctx, m_target);
+  srz_destroy(m_ctx);
+}
 
 int TraditionalRasterizer::textureSlot(const std::shared_ptr<Shader> &sh) {
   TextureLoader *tl = sh->getTextureObject().get();
@@ -523,8 +551,6 @@ void TraditionalRasterizer::draw(Primitive type) {
   }
   const int prim = type == Primitive::LINES ? SRZ_PRIMITIVE_LINES : SRZ_PRIMITIVE_TRIANGLES;
   last_stats = Stats();
-  bool fused = m_justCleared;
-  m_justCleared = false;
   for (auto &kv : m_scenes) {
     Scene &scene = *kv.second;
     if (device_vertex_stage) { // meshes resident on the GPU, vertex stage there (k_vertex)
@@ -574,12 +600,17 @@ void TraditionalRasterizer::draw(Primitive type) {
       sf.zscale = scene.depthScale(), sf.zoffset = scene.depthOffset();
       sf.n_lights = (uint32_t)L.size(), sf.lights = L.data();
       sf.n_draws = (uint32_t)D.size(), sf.draws = D.data();
-      sf.flags = SRZ_EXACT_SPLIT | (fused ? SRZ_FUSED_CLEAR : 0u);
-      fused = false;
+      sf.flags = SRZ_EXACT_SPLIT; // whether the target was just cleared is the target's own state
       srz_stats st{};
-      int rc = srz_draw_scene(m_ctx, prim, &sf, m_zBuffer.data(), m_channels[0].data(), m_channels[1].data(), m_channels[2].data(),
-                              collect_stats ? &st : nullptr);
+      srz_frameset *&set = m_sceneSets[&scene];
+      if (set && srz_sceneset_update(m_ctx, set, &sf, 1) != SRZ_OK) { // structure changed: rebuild
+        srz_frameset_destroy(m_ctx, set);
+        set = nullptr;
+      }
+      if (!set && srz_sceneset_create(m_ctx, &sf, 1, &set) != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+      int rc = srz_target_draw(m_ctx, m_target, prim, set, collect_stats ? &st : nullptr);
       if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+      m_hostStale = true;
       last_stats.n_tris += st.n_tris, last_stats.n_culled += st.n_culled, last_stats.pixel_tests += st.pixel_tests;
       last_stats.fragments += st.fragments, last_stats.shaded += st.shaded, last_stats.visible += st.visible;
       last_stats.visible_textured += st.visible_textured;
@@ -617,12 +648,14 @@ void TraditionalRasterizer::draw(Primitive type) {
     fr.p = Shader::p, fr.kh = Shader::kh, fr.kn = Shader::kn;
     fr.n_lights = (uint32_t)L.size(), fr.lights = L.data();
     fr.n_batches = (uint32_t)B.size(), fr.batches = B.data();
-    fr.flags = SRZ_EXACT_SPLIT | (fused ? SRZ_FUSED_CLEAR : 0u);
-    fused = false; // only the first scene after clear() may skip reading the framebuffer
+    fr.flags = SRZ_EXACT_SPLIT;
     srz_stats st{};
-    int rc = srz_draw(m_ctx, prim, &fr, m_zBuffer.data(), m_channels[0].data(), m_channels[1].data(), m_channels[2].data(),
-                      collect_stats ? &st : nullptr);
+    srz_frameset *tmp = nullptr;
+    if (srz_frameset_create(m_ctx, &fr, 1, &tmp) != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+    int rc = srz_target_draw(m_ctx, m_target, prim, tmp, collect_stats ? &st : nullptr);
+    srz_frameset_destroy(m_ctx, tmp);
     if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
+    m_hostStale = true;
     last_stats.n_tris += st.n_tris, last_stats.n_culled += st.n_culled, last_stats.pixel_tests += st.pixel_tests;
     last_stats.fragments += st.fragments, last_stats.shaded += st.shaded, last_stats.visible += st.visible;
     last_stats.visible_textured += st.visible_textured;

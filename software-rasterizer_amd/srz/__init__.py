@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
-           "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
+           "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
            "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath"]
 
 
@@ -53,6 +53,7 @@ def lib():
         L.srz_frameset_out_bytes.argtypes = [vp, vp]
         L.srz_frameset_out_bytes.restype = C.c_size_t
         L.srz_frameset_render.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint32, vp]
+        L.srz_frameset_resolve8.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
         L.srz_frameset_stats.argtypes = [vp, vp, C.POINTER(abi.SrzStats)]
         L.srz_frameset_algorithmic_bytes.argtypes = [vp, vp]
         L.srz_frameset_algorithmic_bytes.restype = C.c_uint64
@@ -95,6 +96,11 @@ class FrameSet:
         """d_out_ptr: integer device address (e.g. torch_tensor.data_ptr()). Asynchronous."""
         self.ctx._check(lib().srz_frameset_render(self.ctx.h, self.h, C.c_void_p(d_out_ptr), out_bytes, flags,
                                                   C.c_void_p(stream) if stream else None))
+
+    def resolve8(self, d_planes_ptr, d_bgr8_ptr, bgr8_bytes, stream=None):
+        """display()'s 8-bit resolve on the device: planes (render output) → [frame][rows][W][3] uint8."""
+        self.ctx._check(lib().srz_frameset_resolve8(self.ctx.h, self.h, C.c_void_p(d_planes_ptr), C.c_void_p(d_bgr8_ptr), bgr8_bytes,
+                                                    C.c_void_p(stream) if stream else None))
 
     def stats(self):
         st = abi.SrzStats()

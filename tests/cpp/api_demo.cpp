@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -44,6 +45,42 @@ int main(int argc, char **argv) {
     std::printf("covered=%zu fragments=%llu visible=%llu\n", covered, (unsigned long long)render->last_stats.fragments,
                 (unsigned long long)render->last_stats.visible);
     if (covered == 0 || covered != render->last_stats.visible) return 1;
+    // the resolved 8-bit image (device resolve) must equal the host-side rounding of the float planes
+    const auto &bgr = render->frameBuffer8();
+    for (size_t i = 0; i < 256 * 256; ++i)
+      for (int c = 0; c < 3; ++c) {
+        float v = render->channel(c)[i];
+        long r = std::lrintf(v);
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        if (bgr[i * 3 + c] != (unsigned char)r) return 1;
+      }
+    // host vertex stage (loadTriangleStream on the CPU) must give the same planes, bit for bit
+    auto render2 = std::make_shared<SoftRasterizer::TraditionalRasterizer>(256, 256);
+    render2->device_vertex_stage = false;
+    if (!render2->addScene(scene)) return 1;
+    scene->setProjectionMatrix(45.0f, 0.1f, 100.0f);
+    render2->clear(SoftRasterizer::Buffers::Color | SoftRasterizer::Buffers::Depth);
+    render2->draw(SoftRasterizer::Primitive::TRIANGLES);
+    if (std::memcmp(render2->zBuffer().data(), render->zBuffer().data(), 256 * 256 * 4) != 0) return 1;
+    for (int c = 0; c < 3; ++c)
+      if (std::memcmp(render2->channel(c).data(), render->channel(c).data(), 256 * 256 * 4) != 0) return 1;
+    // draw() never clears: a second draw over the same buffers is idempotent; a depth-only clear keeps the colours
+    render->draw(SoftRasterizer::Primitive::TRIANGLES);
+    if (std::memcmp(render2->zBuffer().data(), render->zBuffer().data(), 256 * 256 * 4) != 0) return 1;
+    render->clear(SoftRasterizer::Buffers::Depth);
+    size_t inf = 0;
+    for (float z : render->zBuffer()) inf += std::isinf(z) ? 1 : 0;
+    if (inf != 256 * 256) return 1;
+    if (std::memcmp(render2->channel(1).data(), render->channel(1).data(), 256 * 256 * 4) != 0) return 1;
+    // ten frames of the reference's main loop (src/main.cpp:113-175): clear, set matrices, display
+    for (int k = 0; k < 10; ++k) {
+      degree += 10.0f;
+      render->clear(SoftRasterizer::Buffers::Color | SoftRasterizer::Buffers::Depth);
+      scene->setModelMatrix("spot", glm::vec3(0.f, 1.f, 0.f), degree, glm::vec3(0.0f), glm::vec3(0.3f));
+      scene->setViewMatrix(glm::vec3(0.0f, 0.0f, 0.9f), glm::vec3(0.0f, 0.0f, 0.0f), glm::vec3(0.0f, 1.0f, 0.0f));
+      scene->setProjectionMatrix(45.0f, 0.1f, 100.0f);
+      render->display(SoftRasterizer::Primitive::TRIANGLES);
+    }
     bool threw = false;
     try {
       render->draw(static_cast<SoftRasterizer::Primitive>(7));

@@ -120,3 +120,22 @@ def test_full_size_properties_config2_batch():
     st = fs.stats()
     assert int(cov.sum()) == st["visible"] and (cov > 90_000).all() and (cov < 200_000).all()
     ctx.close()
+
+
+def test_device_resolve8_equals_display_resolve(orc, frames):
+    """RenderingPipeline::display's merge + convertTo(CV_8UC3) on the device vs the oracle's restatement."""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    fs, out = render(ctx, frames)
+    # salt a few values to exercise rounding ties, saturation and NaN
+    out[0, 1, 0, :8] = torch.tensor([0.5, 1.5, 2.5, 254.5, 255.5, 300.0, -3.0, float("nan")], device="cuda")
+    bgr = torch.zeros((fs.n_frames, fs.local_rows, fs.width, 3), dtype=torch.uint8, device="cuda")
+    fs.resolve8(out.data_ptr(), bgr.data_ptr(), bgr.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    got = bgr.cpu().numpy()
+    for i in range(fs.n_frames):
+        assert np.array_equal(got[i], orc.resolve8(tuple(host[i])))
+    assert got[0, 0, :8, 0].tolist() == [0, 2, 2, 254, 255, 255, 0, 0]
+    ctx.close()
