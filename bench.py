@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--scope", choices=["raster", "draw"], default="raster",
                     help="raster: post-MVP triangle streams resident in HBM (BASELINE's hot path); "
                          "draw: meshes + per-frame matrices resident, the vertex stage (k_vertex) is timed too")
+    ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
+                    help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
+                         "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     args = ap.parse_args()
@@ -126,17 +129,26 @@ def main():
 
     out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    gathered = full = None
+    gathered = full = bgr = None
     if world > 1:
-        gathered = torch.empty((world,) + tuple(fs.out_shape), dtype=torch.float32, device="cuda")
         bpr = fs.local_rows // 32
-        full = torch.empty((n_frames, 4, bpr * world * 32, fs.width), dtype=torch.float32, device="cuda")
+        if args.exchange == "planes":
+            gathered = torch.empty((world,) + tuple(fs.out_shape), dtype=torch.float32, device="cuda")
+            full = torch.empty((n_frames, 4, bpr * world * 32, fs.width), dtype=torch.float32, device="cuda")
+        else:  # display()'s 8-bit image: one "plane" of W*3 bytes per row
+            bgr = torch.empty((n_frames, 1, fs.local_rows, fs.width * 3), dtype=torch.uint8, device="cuda")
+            gathered = torch.empty((world,) + tuple(bgr.shape), dtype=torch.uint8, device="cuda")
+            full = torch.empty((n_frames, 1, bpr * world * 32, fs.width * 3), dtype=torch.uint8, device="cuda")
 
     def step():
         fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream)
         if world > 1:
             # band b = local_band*world + rank  →  row-major planes (rows beyond `height` are all-gather padding)
-            parallel.all_gather_frames(out, world, gathered, full)
+            if args.exchange == "planes":
+                parallel.all_gather_frames(out, world, gathered, full)
+            else:
+                fs.resolve8(out.data_ptr(), bgr.data_ptr(), bgr.numel(), stream)
+                parallel.all_gather_frames(bgr, world, gathered, full)
 
     def fence():
         torch.cuda.synchronize()
@@ -180,7 +192,7 @@ def main():
                        "frames_per_step": n_frames, "frames_per_step_per_gpu": args.frames,
                        "triangles_per_frame": n_tris_frame, "lights": 2, "scope": args.scope,
                        "sharding": "whole frames on 1 GPU" if world == 1 else
-                       f"32-row bands round-robin over {world} GPUs + RCCL all-gather + de-interleave (timed)"},
+                       f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {args.exchange} + de-interleave (timed)"},
             "mfragments_per_sec": frag_total / fs.n_frames * fps / 1e6,
             "fragments_per_frame": frag_total / fs.n_frames, "visible_pixels_per_frame": vis_total / fs.n_frames,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
