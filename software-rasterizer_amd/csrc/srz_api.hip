@@ -348,6 +348,11 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   fs->n_frames = n_frames, fs->width = W, fs->height = H;
   fs->shard_rank = ctx->shard_rank, fs->shard_world = ctx->shard_world;
   shard_layout(H, fs->shard_rank, fs->shard_world, fs->n_bands, fs->n_local_bands, fs->bands_per_rank, fs->local_rows);
+  fs->tiles_x = (uint32_t)((W + TILE - 1) / TILE);
+  if ((uint64_t)((n_frames + 7) / 8 * 8) * fs->n_local_bands * fs->tiles_x >= 0x7fffffffull) {
+    delete fs;
+    return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: frames x tiles exceeds the launch grid limit; split the batch");
+  }
   uint64_t tri_off = 0, light_off = 0, batch_off = 0, list_off = 0, count_off = 0;
   for (int f = 0; f < n_frames; ++f) {
     const srz_frame &fr = frames[f];
@@ -375,7 +380,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
       fs->h_batches.push_back(BatchDesc{sb.shader, sb.tex_id, (uint32_t)nt, sb.n_tris});
       nt += sb.n_tris;
     }
-    if (tri_off + nt > 0xfffffff0ull) return bad("too many triangles");
+    if (tri_off + nt > 0xfffffff0ull || nt >= 0x7fffffffull) return bad("too many triangles");
     d.n_tris = (uint32_t)nt;
     d.n_local_bands = fs->n_local_bands;
     d.list_off = list_off, d.count_off = (uint32_t)count_off;
@@ -412,7 +417,6 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_tri_batch, sizeof(uint16_t) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));
-  fs->tiles_x = (uint32_t)((W + TILE - 1) / TILE);
   fs->max_tiles = (uint32_t)n_frames * fs->n_local_bands * fs->tiles_x;
   FS_TRY(dev_alloc((void **)&fs->d_band_recs, sizeof(RasterRec) * list_off));
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));

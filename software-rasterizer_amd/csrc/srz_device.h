@@ -10,7 +10,6 @@ namespace srz {
 
 constexpr int TILE = 32;             // one wavefront owns one 32x32-pixel tile (its z + owner planes live in LDS)
 constexpr int BAND = 32;             // band = one row of tiles; the unit of multi-GPU sharding and of binning
-constexpr int WAVES_PER_WG = 4;      // k_bands: 4 bands per workgroup
 constexpr int RASTER_WAVES = 1;      // k_raster: ONE wave (= one tile) per workgroup, so a long tile never pins the LDS /
                                      // wave slots of finished neighbours and the dispatcher load-balances tile by tile
 constexpr int LDS_STRIDE = 40;       // padded LDS row stride in dwords: 4 consecutive rows x 8 columns hit 32 distinct banks
