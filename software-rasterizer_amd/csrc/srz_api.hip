@@ -43,6 +43,8 @@ struct srz_ctx {
   unsigned long long dbg[ST_COUNT] = {};
   unsigned long long *d_timeline = nullptr; // diagnostic buffer (srz_debug_timeline)
   size_t timeline_cap = 0;
+  hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct srz_target {
@@ -68,7 +70,9 @@ struct srz_frameset {
   srz_light *d_lights = nullptr;
   RasterRec *d_band_recs = nullptr;
   uint32_t *d_band_count = nullptr;
-  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr;
+  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_tile_mask = nullptr;
+  uint8_t *d_tile_state = nullptr;
+  uint32_t mask_words = 0, state_stride = 0;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
   std::vector<DrawDesc> h_draws;
@@ -117,6 +121,8 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_vis);
   (void)hipFree(fs->d_worklist);
   (void)hipFree(fs->d_work_count);
+  (void)hipFree(fs->d_tile_mask);
+  (void)hipFree(fs->d_tile_state);
   (void)hipFree(fs->d_sdesc);
   (void)hipFree(fs->d_draws);
   (void)hipFree(fs->d_band_count);
@@ -136,6 +142,10 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.vis = fs->d_vis;
   a.worklist = fs->d_worklist;
   a.work_count = fs->d_work_count;
+  a.tile_mask = fs->d_tile_mask;
+  a.mask_words = fs->mask_words;
+  a.tile_state = fs->d_tile_state;
+  a.state_stride = fs->state_stride;
   a.tiles_x = fs->tiles_x;
   a.n_local_bands = fs->n_local_bands;
   a.n_frames = (uint32_t)fs->n_frames;
@@ -216,9 +226,28 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
   launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, fs->max_tris, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
+  // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in line (small jobs)
+  const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
+                         std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
+  const bool side = any_fused && fs->max_tiles >= 8192;
+  if (side) {
+    if (!ctx->stream2) {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    launch_clear(a, fs->max_tiles, true, ctx->stream2);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+  } else if (any_fused) {
+    launch_clear(a, fs->max_tiles, false, s);
+  }
   launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
+  launch_lists(a, fs->n_frames, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, s);
+  if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -290,6 +319,7 @@ void srz_destroy(srz_ctx *ctx) {
   for (int i = 0; i < MAX_MESH; ++i) (void)hipFree(ctx->mesh[i].d_verts), (void)hipFree(ctx->mesh[i].d_faces);
   (void)hipFree(ctx->d_tex);
   (void)hipFree(ctx->d_stats);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2), (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_join);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -422,6 +452,11 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
   FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
   FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t)));
+  fs->mask_words = (fs->tiles_x + 31u) / 32u;
+  FS_TRY(dev_alloc((void **)&fs->d_tile_mask, sizeof(uint32_t) * (size_t)n_frames * fs->n_local_bands * fs->mask_words));
+  fs->state_stride = (fs->n_local_bands * fs->tiles_x + 15u) & ~15u;
+  FS_TRY(dev_alloc((void **)&fs->d_tile_state, (size_t)n_frames * fs->state_stride));
+  FS_TRY(hipMemset(fs->d_tile_state, 0, (size_t)n_frames * fs->state_stride));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_band_count, sizeof(uint32_t) * count_off));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));

@@ -40,6 +40,7 @@ template <typename T> __device__ __forceinline__ const SRZ_CAS T *as_const(const
 // native vector types (HIP's float4/uint2 classes cannot be loaded through an address-space-qualified pointer)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- operand-order-exact min/max (SSE / std:: semantics, see oracle) ------------------------------------------
 __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
@@ -266,7 +267,8 @@ constexpr int BANDS_MAX_WAVES = 16;
 constexpr int BANDS_MAX_CHUNKS = 2048; // chunk counters held in LDS per super-block (= 131072 triangles)
 
 // launched with 4..16 waves per workgroup (small streams do not pay for idle waves) and
-// dynamic LDS = (3 * chunks_cap + 256 * waves + 2) dwords: [hit masks (u64) | offsets | per-wave index/slot queues | total]
+// dynamic LDS = (3 * chunks_cap + 256 * waves + 2 + mask_words) dwords:
+//   [hit masks (u64) | offsets | per-wave index/slot queues | total | tile mask]
 __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, RasterRec *band_recs, uint32_t *band_count,
                                                                 uint32_t chunks_cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -275,11 +277,15 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
   uint32_t *s_off = s_dyn + 2 * chunks_cap;                                   // after the scan: exclusive offset per chunk
   uint32_t *s_q = s_off + chunks_cap;
   uint32_t &s_total = s_q[256 * BANDS_WAVES];
+  uint32_t *s_tmask = s_q + 256 * BANDS_WAVES + 2; // tiles of this band overlapped by some listed bbox
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lb = blockIdx.x;
   if (lb >= fd->n_local_bands) return; // workgroup-uniform
+  for (uint32_t w = threadIdx.x; w < a.mask_words; w += blockDim.x) s_tmask[w] = 0u;
+  __syncthreads();
+  const int Wm1 = fd->width - 1;
   const uint32_t n_tris = fd->n_tris;
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
@@ -308,6 +314,11 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
       rec.cx = p[6], rec.cy = p[7], rec.z2 = p[8];
       rec.bbx = r.x, rec.bby = r.y, rec.idx = t;
       out[pos] = rec;
+      const int tlo = max((int)(int16_t)(r.x & 0xffff), 0) >> 5, thi = min((int)(int16_t)(r.y & 0xffff), Wm1) >> 5;
+      for (int w = tlo >> 5; w <= (thi >> 5); ++w) { // (one word unless the bbox straddles a 1024-pixel boundary)
+        const int b0 = max(tlo - w * 32, 0), b1 = min(thi - w * 32, 31);
+        if (b0 <= b1) atomicOr(&s_tmask[w], (0xffffffffu >> (31 - b1)) & (0xffffffffu << b0));
+      }
     }
   };
   const uint32_t n_chunks = (n_tris + 63) / 64;
@@ -366,6 +377,8 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
     __syncthreads(); // s_off / s_total are reused by the next super-block
   }
   if (threadIdx.x == 0) band_count[fd->count_off + lb] = base;
+  for (uint32_t w = threadIdx.x; w < a.mask_words; w += blockDim.x) // (the loop's last barrier ordered the atomics)
+    a.tile_mask[((size_t)blockIdx.y * a.n_local_bands + lb) * a.mask_words + w] = s_tmask[w];
 }
 
 // ================================================================================================================
@@ -622,10 +635,17 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   const int ty0 = band * BAND;
   const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
   const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
+  {  // no bbox of the band list reaches this tile: nothing to rasterise, and its clear (if any) is k_clear's job
+    const uint32_t txi = (uint32_t)tx0 / TILE;
+    const uint32_t word = as_const(a.tile_mask)[((size_t)frame * a.n_local_bands + lb) * a.mask_words + (txi >> 5)];
+    if (!((word >> (txi & 31u)) & 1u)) {
+      if (lane == 0) a.tile_state[(size_t)frame * a.state_stride + tile] = 0;
+      return;
+    }
+  }
   float *zl = s_z[wave];
   uint32_t *il = s_id[wave];
 
-  const size_t plane = (size_t)a.local_rows * (size_t)W;
   const size_t row0 = (size_t)lb * BAND;
   float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
   uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
@@ -793,6 +813,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
   const bool vec_ok = (W & 3) == 0;
   if ((tile_has_owner || fused) && !(flags & 0x400u)) {
+    const size_t plane = (size_t)a.local_rows * (size_t)W;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int it = 0; it < 4; ++it) {
       const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
@@ -813,7 +834,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
           SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
         }
-      } else {
+      } else { // touched by a bbox but owned by nobody: the clear itself
         if (full) {
           store_nt(gz, z4);
           store_nt(gz + plane, zero4);
@@ -828,10 +849,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
       }
     }
   }
-  if (tile_has_owner && lane == 0) {
-    const uint32_t slot = atomicAdd(a.work_count, 1u);
-    a.worklist[slot] = (frame * a.n_local_bands + lb) * a.tiles_x + (uint32_t)(tx0 / TILE);
-  }
+  // (no worklist append here: 10^5 tiles bumping one counter serialise at ~10 ns each; k_lists compacts the states)
+  if (lane == 0) a.tile_state[(size_t)frame * a.state_stride + tile] = tile_has_owner ? 1 : 0;
   if (a.timeline && lane == 0) { // diagnostic: per-tile residency (srz_debug_timeline)
     unsigned hw = 0;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -863,6 +882,81 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
 // the back), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
 // colours go to LDS planes and leave as coalesced 16-byte stores.
 // ================================================================================================================
+// ================================================================================================================
+// k_lists — one WAVE per frame turns k_raster's per-tile states (one byte per tile, rows padded to 16) into the dense
+// worklist k_shade walks: 16 states per lane in one load, wave prefix sum, ONE atomic per 1024 tiles, fill.
+// ================================================================================================================
+__global__ __launch_bounds__(64) void k_lists(RenderArgs a) {
+  const uint32_t f = blockIdx.x, tpf = a.n_local_bands * a.tiles_x;
+  const int lane = threadIdx.x;
+  const SRZ_CAS uint8_t *st = as_const(a.tile_state) + (size_t)f * a.state_stride;
+  for (uint32_t t0 = 0; t0 < tpf; t0 += 1024) {
+    const uint32_t t = t0 + (uint32_t)lane * 16u;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (t < tpf) { // (padding bytes are zero)
+      const u32x4 q = *reinterpret_cast<const SRZ_CAS u32x4 *>(st + t);
+      w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+    }
+    const uint32_t n = (uint32_t)(__popc(w[0] & 0x01010101u) + __popc(w[1] & 0x01010101u) + __popc(w[2] & 0x01010101u) +
+                                  __popc(w[3] & 0x01010101u));
+    uint32_t incl = n;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.work_count, total);
+    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - n;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if ((w[k >> 2] >> ((k & 3) * 8)) & 1u) a.worklist[pos++] = f * tpf + t + (uint32_t)k;
+  }
+}
+
+// The clear of one tile nobody owns (z = +inf, colour 0; src/Render.cpp:46-55 restricted to the tile): pure 16-byte
+// streaming stores, issued by k_shade between two shaded tiles so that they drain under the shading arithmetic.
+__device__ __forceinline__ void clear_tile(const RenderArgs &a, uint32_t e, int tid) {
+  const uint32_t tx = e % a.tiles_x, rest = e / a.tiles_x;
+  const uint32_t lb = rest % a.n_local_bands, f = rest / a.n_local_bands;
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
+  const int W = fd->width, H = fd->height;
+  const int band = (int)lb * a.shard_world + a.shard_rank;
+  const int tx0 = (int)tx * TILE, ty0 = band * BAND;
+  const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
+  const size_t plane = (size_t)a.local_rows * (size_t)W;
+  const int ly = tid >> 3, lx4 = (tid & 7) * 4;
+  const int y = ty0 + ly, x4 = tx0 + lx4;
+  if (y > ty1 || x4 > tx1) return;
+  float *gz = a.out + (size_t)f * a.frame_stride + ((size_t)lb * BAND + ly) * (size_t)W + x4;
+  const float inf = __builtin_inff();
+  if (((W & 3) == 0) && x4 + 3 <= tx1) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    store_nt(gz, make_float4(inf, inf, inf, inf));
+    store_nt(gz + plane, zero4);
+    store_nt(gz + 2 * plane, zero4);
+    store_nt(gz + 3 * plane, zero4);
+  } else {
+    for (int k = 0; k < 4; ++k)
+      if (x4 + k <= tx1) gz[k] = inf, gz[plane + k] = 0.f, gz[2 * plane + k] = 0.f, gz[3 * plane + k] = 0.f;
+  }
+}
+
+// k_clear — the fused clear of every tile NO bbox reaches (k_bands' tile masks), i.e. most of the framebuffer.  It runs
+// on a second stream NEXT TO k_raster, which skips those tiles: no LDS and < 32 VGPRs, so its waves fit beside the
+// rasteriser's on every CU and the bulk of the frame's HBM writes drains under the visibility arithmetic.
+__global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
+  const uint32_t tpf = a.n_local_bands * a.tiles_x, total = a.n_frames * tpf;
+  for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+    const uint32_t tx = e % a.tiles_x, row = e / a.tiles_x; // row = frame * n_local_bands + lb
+    const uint32_t word = as_const(a.tile_mask)[(size_t)row * a.mask_words + (tx >> 5)];
+    if ((word >> (tx & 31u)) & 1u) continue;
+    const uint32_t flags = as_const(a.frames)[row / a.n_local_bands].flags | a.flags_or;
+    if (flags & SRZ_FUSED_CLEAR) clear_tile(a, e, threadIdx.x);
+  }
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
@@ -873,7 +967,7 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t n_work = *as_const(a.work_count);
+  const uint32_t n_work = as_const(a.work_count)[0];
   unsigned long long n_vis = 0, n_vis_tex = 0;
   for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
     const uint32_t e = as_const(a.worklist)[w];
@@ -1123,8 +1217,22 @@ void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_coun
   const uint32_t n_chunks = (max_tris + 63) / 64;
   const uint32_t cap = n_chunks < 1 ? 1 : (n_chunks > (uint32_t)BANDS_MAX_CHUNKS ? (uint32_t)BANDS_MAX_CHUNKS : n_chunks);
   const int waves = n_chunks <= 256 ? 4 : (n_chunks <= 1024 ? 8 : BANDS_MAX_WAVES);
-  const size_t lds = sizeof(uint32_t) * (3u * (size_t)cap + 256u * waves + 2u);
+  const size_t lds = sizeof(uint32_t) * (3u * (size_t)cap + 256u * waves + 2u + a.mask_words);
   hipLaunchKernelGGL(k_bands, grid, dim3(64 * waves), lds, s, a, band_recs, band_count, cap);
+}
+
+void launch_lists(const RenderArgs &a, int n_frames, hipStream_t s) {
+  if (n_frames > 0 && a.n_local_bands) hipLaunchKernelGGL(k_lists, dim3((uint32_t)n_frames), dim3(64), 0, s, a);
+}
+
+void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s) {
+  if (max_tiles == 0) return;
+  // Beside k_raster/k_shade the clear is THROTTLED by its grid size: ~160 workgroups write at roughly half the HBM
+  // rate, so the stores spread over the whole pipeline instead of starving the rasteriser's loads (measured on
+  // MI355X, 256 frames of 1024^2: 64 WGs → clear outlives k_shade, 1024 → k_raster +80 %; flat optimum 128..192).
+  static const uint32_t env = getenv("SRZ_CLEAR_WGS") ? (uint32_t)atoi(getenv("SRZ_CLEAR_WGS")) : 0u;
+  const uint32_t cap = !beside_raster ? 2048u : (env ? env : 160u);
+  hipLaunchKernelGGL(k_clear, dim3(max_tiles < cap ? max_tiles : cap), dim3(256), 0, s, a);
 }
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s) {
