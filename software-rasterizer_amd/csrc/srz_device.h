@@ -76,7 +76,7 @@ struct TexDesc {
 
 // counters accumulated by the STATS kernel variants (same order as srz_stats)
 enum { ST_TRIS = 0, ST_CULLED, ST_PIXEL_TESTS, ST_FRAGMENTS, ST_SHADED, ST_VISIBLE, ST_VISIBLE_TEX,
-       ST_DBG_CYC_A, ST_DBG_CYC_B, ST_DBG_CYC_C, ST_DBG_MAX_WAVE, ST_DBG_SHADE_CALLS, ST_DBG_BLOCKS, ST_COUNT };
+       ST_DBG_CYC_A, ST_DBG_CYC_B, ST_DBG_CYC_C, ST_DBG_MAX_WAVE, ST_DBG_IEEE_TILES, ST_DBG_BLOCKS, ST_COUNT };
 
 struct RenderArgs {
   const FrameDesc *frames;

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -84,24 +85,67 @@ __device__ __forceinline__ float rsqrt2_rn(float d) {
   return rsqrt2_ieee(d);
 }
 
+// ---- math policies of the shading code ---------------------------------------------------------------------------
+// The shaders are written once against a policy M that supplies the correctly rounded 1/x, sqrt(x), 1/sqrt(x):
+//   BranchMath  a wave-uniform branch per operation (k_setup / k_raster: one or two operations per thread)
+//   FastMath    OPTIMISTIC: always the short exact sequence, the operand checks only accumulate into `bad`; k_shade
+//               re-shades the (in practice never taken) chunk with IeeeMath when any lane saw an out-of-range operand.
+//               No branches inside the shader, so the independent normalisations of one pixel interleave.
+//   IeeeMath    the compiler's full IEEE expansions.
+// All three return identical bits wherever FastMath's checks pass (tests/test_gpu_fastmath.py).
+__device__ __forceinline__ bool fast_pos(float x) { return ((f2u_(x) >> 23) - 27u) <= 200u; } // fast_range and x > 0
+struct BranchMath {
+  __device__ __forceinline__ float rcp(float x) { return rcp_rn(x); }
+  __device__ __forceinline__ float sqrt(float x) { return sqrt_rn(x); }
+  __device__ __forceinline__ float rsqrt2(float d) { return rsqrt2_rn(d); }
+};
+struct IeeeMath {
+  __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
+  __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+  __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
+};
+struct FastMath {
+  bool bad = false;
+  __device__ __forceinline__ float rcp(float x) {
+    bad |= !fast_range(x);
+    return rcp_core(x);
+  }
+  __device__ __forceinline__ float sqrt(float x) {
+    bad |= !fast_pos(x);
+    return sqrt_core(x);
+  }
+  __device__ __forceinline__ float rsqrt2(float d) { // sqrt(d) lies in [2^-50, 2^50]: inside rcp_core's range
+    bad |= !fast_pos(d);
+    return rcp_core(sqrt_core(d));
+  }
+};
+
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
   float tx = ax * bx, ty = ay * by, tz = az * bz;
   return tx + ty + tz;
 }
 // glm::normalize: v * (1/sqrt(dot(v,v)))
-__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
-  float is = rsqrt2_rn(dot3(x, y, z, x, y, z));
+template <class M> __device__ __forceinline__ void normalize3(M &m, float &x, float &y, float &z) {
+  float is = m.rsqrt2(dot3(x, y, z, x, y, z));
   x = x * is, y = y * is, z = z * is;
 }
 // NormalSIMD::normalized (src/Tools.cpp:13-24)
-__device__ __forceinline__ void v_normalized(float &x, float &y, float &z) {
-  float len = sqrt_rn(fmaf_(x, x, fmaf_(y, y, z * z)));
+template <class M> __device__ __forceinline__ void v_normalized(M &m, float &x, float &y, float &z) {
+  float len = m.sqrt(fmaf_(x, x, fmaf_(y, y, z * z)));
   if (len > 0.0f) {
-    float inv = rcp_rn(len);
+    float inv = m.rcp(len);
     x = x * inv, y = y * inv, z = z * inv;
   } else {
     x = y = z = 0.0f;
   }
+}
+
+// FastMath: a squared length inside the fast range has a positive, in-range square root — one check covers both steps
+__device__ __forceinline__ void v_normalized(FastMath &m, float &x, float &y, float &z) {
+  const float d = fmaf_(x, x, fmaf_(y, y, z * z));
+  m.bad |= !fast_pos(d);
+  const float inv = rcp_core(sqrt_core(d));
+  x = x * inv, y = y * inv, z = z * inv;
 }
 
 // pow evaluated in binary64 and rounded once to binary32 (== correctly rounded powf in all but ~1e-7 of cases).
@@ -131,9 +175,9 @@ struct TriXY {
   float v_inv;  // 1 / fmsub(ABx,ACy,ACx*ABy)   — "V" (8-wide) path, src/Rasterizer.cpp:111-112
   float s_area; // ABx*ACy - ABy*ACx              — "S" (scalar tail) path, src/Rasterizer.cpp:61
 };
-__device__ __forceinline__ void tri_consts(TriXY &t) {
+template <class M> __device__ __forceinline__ void tri_consts(M &m, TriXY &t) {
   float ABx = t.bx - t.ax, ABy = t.by - t.ay, ACx = t.cx - t.ax, ACy = t.cy - t.ay;
-  t.v_inv = rcp_rn(fmsubf(ABx, ACy, ACx * ABy));
+  t.v_inv = m.rcp(fmsubf(ABx, ACy, ACx * ABy));
   t.s_area = ABx * ACy - ABy * ACx;
 }
 
@@ -221,7 +265,8 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
     if (finite) {
       float e1x = B0 - A0, e1y = B1 - A1, e1z = B2 - A2, e2x = C0 - A0, e2y = C1 - A1, e2z = C2 - A2;
       float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
-      normalize3(nx, ny, nz);
+      BranchMath bm;
+      normalize3(bm, nx, ny, nz);
       keep = !(dot3(nx, ny, nz, ex, ey, ez) > 0.0f);
     }
     if (keep) {
@@ -395,17 +440,18 @@ struct ShadeDesc { // what a batch's Shader object holds: type + texture (Shader
 };
 
 // BlinnPhong<__m256> for one light (include/shader/Shader.hpp:104-229)
-__device__ __forceinline__ void v_blinn_phong(float nx, float ny, float nz, const FrameK &K, float kdr, float kdg, float kdb,
+template <class M>
+__device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz, const FrameK &K, float kdr, float kdg, float kdb,
                                               const SRZ_CAS srz_light *L, float px, float py, float pz, float &o0, float &o1,
                                               float &o2) {
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
   float lx = Lx - px, ly = Ly - py, lz = Lz - pz;
-  float att = rsqrt2_rn(fmaf_(lx, lx, ly * ly));
+  float att = m.rsqrt2(fmaf_(lx, lx, ly * ly));
   float d0 = I0 * att, d1 = I1 * att, d2 = I2 * att;
   float hx = lx + (K.eye[0] - px), hy = ly + (K.eye[1] - py), hz = lz + (K.eye[2] - pz);
-  v_normalized(hx, hy, hz);
+  v_normalized(m, hx, hy, hz);
   float nlx = lx, nly = ly, nlz = lz;
-  v_normalized(nlx, nly, nlz);
+  v_normalized(m, nlx, nly, nlz);
   float cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
   float cosT = pow_cr(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
   o0 = kdr * fmaf_(K.ka[0], I0, fmaf_(d0 * kdr, cosA, (d0 * K.ks[0]) * cosT));
@@ -414,7 +460,8 @@ __device__ __forceinline__ void v_blinn_phong(float nx, float ny, float nz, cons
 }
 
 // Shader::applyFragmentShader SIMD overload + simd_*_impl (src/Shader.cpp:128-386); colour out in [0,255]
-__device__ __forceinline__ void v_shade(const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
+template <class M>
+__device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
   float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f;
   if (sd.shader == SRZ_SHADER_NORMAL) {
@@ -435,7 +482,7 @@ __device__ __forceinline__ void v_shade(const FrameK &K, const ShadeDesc &sd, fl
     c0 = c1 = c2 = 0.0f;
     for (uint32_t l = 0; l < K.n_lights; ++l) {
       float o0, o1, o2;
-      v_blinn_phong(nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
+      v_blinn_phong(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
   }
@@ -460,21 +507,22 @@ __device__ __forceinline__ void s_texel(const ShadeDesc &sd, float u, float v, f
 }
 
 // Shader::BlinnPhong scalar (src/Shader.cpp:510-543); the two std::pow(x,2) and the sqrt are binary64 there
-__device__ __forceinline__ void s_blinn_phong(const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
+template <class M>
+__device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
                                               float kd0, float kd1, float kd2, const SRZ_CAS srz_light *L, float &o0, float &o1,
                                               float &o2) {
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
-  normalize3(nx, ny, nz);
+  normalize3(m, nx, ny, nz);
   float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
   double dx = (double)(Lx - px), dy = (double)(Ly - py);
   float dsq = (float)__builtin_sqrt(dx * dx + dy * dy);
   float d0 = I0 / dsq, d1 = I1 / dsq, d2 = I2 / dsq;
   float nlx = ldx, nly = ldy, nlz = ldz;
-  normalize3(nlx, nly, nlz);
+  normalize3(m, nlx, nly, nlz);
   float cosTheta = std_max(0.0f, dot3(nx, ny, nz, nlx, nly, nlz));
   float vx = K.eye[0] - px, vy = K.eye[1] - py, vz = K.eye[2] - pz;
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
-  normalize3(hx, hy, hz);
+  normalize3(m, hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
   float pw = pow_cr(cosAlpha, K.p);
   o0 = ((K.ka[0] * I0 + (cosTheta * kd0) * d0) + (pw * K.ks[0]) * d0) * kd0;
@@ -483,7 +531,8 @@ __device__ __forceinline__ void s_blinn_phong(const FrameK &K, float px, float p
 }
 
 // calcBumpMapping / calcDisplacementMapping common part (src/Shader.cpp:447-507)
-__device__ __forceinline__ void s_bump_common(const ShadeDesc &sd, float nx, float ny, float nz, float u, float v, float kh,
+template <class M>
+__device__ __forceinline__ void s_bump_common(M &m, const ShadeDesc &sd, float nx, float ny, float nz, float u, float v, float kh,
                                               float kn, float &ox, float &oy, float &oz, float &origin_norm) {
   float sq = __builtin_sqrtf(nx * nx + nz * nz);
   float t0 = (nx * ny) / sq, t1 = sq, t2 = (nz * ny) / sq;
@@ -497,16 +546,17 @@ __device__ __forceinline__ void s_bump_common(const ShadeDesc &sd, float nx, flo
   float dV = kh * kn * (__builtin_sqrtf(dot3(w0, w1, w2, w0, w1, w2)) - on);
   float l0 = -dU, l1 = -dV, l2 = 1.0f;
   ox = t0 * l0 + t1 * l1 + t2 * l2, oy = b0 * l0 + b1 * l1 + b2 * l2, oz = nx * l0 + ny * l1 + nz * l2;
-  normalize3(ox, oy, oz);
+  normalize3(m, ox, oy, oz);
   origin_norm = on;
 }
 
 // scalar applyFragmentShader + standard_*_impl + Tools::normalizedToRGB (src/Shader.cpp:547-640, src/Tools.cpp:94-104)
-__device__ __forceinline__ void s_shade(const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
+template <class M>
+__device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   if (sd.shader == SRZ_SHADER_NORMAL) {
-    normalize3(nx, ny, nz);
+    normalize3(m, nx, ny, nz);
     c0 = (nx + 1.0f) / 2.0f, c1 = (ny + 1.0f) / 2.0f, c2 = (nz + 1.0f) / 2.0f;
   } else if (sd.shader >= SRZ_SHADER_TEXTURE && sd.shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
@@ -514,15 +564,15 @@ __device__ __forceinline__ void s_shade(const FrameK &K, const ShadeDesc &sd, fl
     if (sd.shader != SRZ_SHADER_PHONG) s_texel(sd, u, v, kd0, kd1, kd2);
     if (sd.shader == SRZ_SHADER_BUMP) {
       float on;
-      s_bump_common(sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
+      s_bump_common(m, sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
     } else if (sd.shader == SRZ_SHADER_DISPLACEMENT) {
       float on;
-      s_bump_common(sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
+      s_bump_common(m, sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
       sx = px + (K.kn * nx) * on, sy = py + (K.kn * ny) * on, sz = pz + (K.kn * nz) * on;
     }
     for (uint32_t l = 0; l < K.n_lights; ++l) {
       float o0, o1, o2;
-      s_blinn_phong(K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
+      s_blinn_phong(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
   }
@@ -552,47 +602,77 @@ struct TriAttr {
   TriXY t;
   float n0x, n0y, n0z, n1x, n1y, n1z, n2x, n2y, n2z, u0, v0, u1, v1, u2, v2;
 };
-__device__ __forceinline__ void unpack_tri(const TriFetch &f, TriAttr &a) {
+template <class M> __device__ __forceinline__ void unpack_tri(M &m, const TriFetch &f, TriAttr &a) {
   // pos: q0.xyz q0.w q1.xy q1.zw q2.x | nrm: q2.yzw q3.xyz q3.w q4.xy | uv: q4.zw q5.xy q5.zw
   a.t.ax = f.q0.x, a.t.ay = f.q0.y, a.t.z0 = f.q0.z, a.t.bx = f.q0.w, a.t.by = f.q1.x, a.t.z1 = f.q1.y, a.t.cx = f.q1.z,
   a.t.cy = f.q1.w, a.t.z2 = f.q2.x;
-  tri_consts(a.t);
+  tri_consts(m, a.t);
   a.n0x = f.q2.y, a.n0y = f.q2.z, a.n0z = f.q2.w, a.n1x = f.q3.x, a.n1y = f.q3.y, a.n1z = f.q3.z, a.n2x = f.q3.w, a.n2y = f.q4.x,
   a.n2z = f.q4.y;
   a.u0 = f.q4.z, a.v0 = f.q4.w, a.u1 = f.q5.x, a.v1 = f.q5.y, a.u2 = f.q5.z, a.v2 = f.q5.w;
 }
 // Shade pixel (x,y) of depth z, owner `f`, 8-wide ("V") semantics (src/Rasterizer.cpp:380-389)
-__device__ __forceinline__ void shade_pixel_v(const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
+template <class M>
+__device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
-  unpack_tri(f, a);
+  unpack_tri(m, f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
   cover_v(a.t, fx, fy, alpha, beta, gamma, zz);
   float nx = fmaf_(alpha, a.n0x, fmaf_(beta, a.n1x, gamma * a.n2x));
   float ny = fmaf_(alpha, a.n0y, fmaf_(beta, a.n1y, gamma * a.n2y));
   float nz = fmaf_(alpha, a.n0z, fmaf_(beta, a.n1z, gamma * a.n2z));
-  v_normalized(nx, ny, nz);
+  v_normalized(m, nx, ny, nz);
   float u = fmaf_(alpha, a.u0, fmaf_(beta, a.u1, gamma * a.u2));
   float v = fmaf_(alpha, a.v0, fmaf_(beta, a.v1, gamma * a.v2));
-  v_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+  v_shade(m, K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
 }
 // scalar-tail ("S") semantics (src/Rasterizer.cpp:470-492)
-__device__ __forceinline__ void shade_pixel_s(const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
+template <class M>
+__device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
-  unpack_tri(f, a);
+  unpack_tri(m, f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
   cover_s(a.t, fx, fy, alpha, beta, gamma, zz);
   float nx = alpha * a.n0x + beta * a.n1x + gamma * a.n2x;
   float ny = alpha * a.n0y + beta * a.n1y + gamma * a.n2y;
   float nz = alpha * a.n0z + beta * a.n1z + gamma * a.n2z;
-  normalize3(nx, ny, nz);
+  normalize3(m, nx, ny, nz);
   float u = alpha * a.u0 + beta * a.u1 + gamma * a.u2;
   float v = alpha * a.v0 + beta * a.v1 + gamma * a.v2;
-  s_shade(K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+  s_shade(m, K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
 }
+
+#ifdef SRZ_ISA_PROBE
+// instruction-count probes (make asm-probe): the two per-pixel shading paths in isolation
+__global__ void probe_v(RenderArgs a, float *o) {
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames);
+  FrameK K;
+  K.eye[0] = fd->eye[0], K.eye[1] = fd->eye[1], K.eye[2] = fd->eye[2];
+  K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
+  K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
+  K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
+  K.lights = as_const(a.lights);
+  TriFetch tf;
+  fetch_tri(as_const(a.tris), as_const(a.tri_batch), threadIdx.x, tf);
+  ShadeDesc sd;
+  sd.shader = SRZ_SHADER_TEXTURE, sd.tw = 1024, sd.th = 1024, sd.tex = as_const((const uint32_t *)a.vis);
+  float r0, r1, r2;
+#ifdef SRZ_PROBE_S
+  FastMath fm;
+  shade_pixel_s(fm, K, sd, tf, threadIdx.x, blockIdx.x, o[threadIdx.x], r0, r1, r2);
+  if (fm.bad) r0 = -1.f;
+#else
+  FastMath fm;
+  shade_pixel_v(fm, K, sd, tf, threadIdx.x, blockIdx.x, o[threadIdx.x], r0, r1, r2);
+  if (fm.bad) r0 = -1.f;
+#endif
+  o[threadIdx.x] = r0 + r1 + r2;
+}
+#endif
 
 // ================================================================================================================
 // k_raster — VISIBILITY: one wave per 32x32 tile
@@ -702,7 +782,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
     //   whichever needs the fewest blocks)
     uint32_t geom = 0;
     if (hit) {
-      tri_consts(t);
+      BranchMath bm;
+      tri_consts(bm, t);
       const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
       const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
       const int v = min(max(vend - tx0, x0), x1 + 1);
@@ -957,13 +1038,16 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
   }
 }
 
+#ifndef SRZ_SHADE_MINW
+#define SRZ_SHADE_MINW 1
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
+__global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) float s_zv[TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];
-  __shared__ uint32_t s_cnt[2];
+  __shared__ uint32_t s_cnt[3]; // V count, S count, "some operand left FastMath's range"
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1005,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
     const uint32_t *gv = vis0 + (size_t)ly * W + x4;
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), C0 = z4, C1 = z4, C2 = z4;
     uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
-    if (tid == 0) s_cnt[0] = 0, s_cnt[1] = 0;
+    if (tid == 0) s_cnt[0] = 0, s_cnt[1] = 0, s_cnt[2] = 0;
     if (full) {
       z4 = *reinterpret_cast<const float4 *>(gz);
       id4 = *reinterpret_cast<const uint4 *>(gv);
@@ -1050,49 +1134,58 @@ __global__ __launch_bounds__(256) void k_shade(RenderArgs a) {
     const uint32_t nV = s_cnt[0], nS = s_cnt[1];
 
     // ---- 2. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
-    //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial ---
+    //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
+    //         First with the optimistic FastMath; a tile where any operand left the fast range (degenerate normals,
+    //         a light straight above a pixel, ...) is shaded again with the IEEE expansions.
     const uint32_t cV = (nV + 63) >> 6, cS = (nS + 63) >> 6;
-    for (uint32_t c = (uint32_t)wave; c < cV + cS; c += 4) {
-      if (c < cV) {
-        const uint32_t i = c * 64 + lane;
-        if (i < nV) {
-          const uint32_t p = s_list[i];
-          const uint32_t id = s_ids[p];
-          float r0 = 1.f, r1 = 2.f, r2 = 3.f;
-          ShadeDesc sd;
-          sd.shader = 0;
-          if (!(flags & 0x800u)) {
+    // (one loop per class: a single loop over both keeps the registers of the V and of the S shader alive together)
+    auto class_pass = [&](auto policy, auto is_v, bool count) -> bool {
+      using M = decltype(policy);
+      constexpr bool isV = decltype(is_v)::value;
+      bool bad = false;
+      for (uint32_t c = (uint32_t)wave; c < cV + cS; c += 4) { // chunk c of the tile: V chunks first, then S chunks
+        if ((c < cV) != isV) continue;
+        const uint32_t i = (isV ? c : c - cV) * 64 + lane;
+        if (i >= (isV ? nV : nS)) continue;
+        const uint32_t p = s_list[isV ? i : TILE * TILE - 1 - i];
+        const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
+        float r0 = 1.f, r1 = 2.f, r2 = 3.f;
+        ShadeDesc sd;
+        sd.shader = 0;
+        if (!(flags & 0x800u)) {
           TriFetch tf;
           fetch_tri(tris, tri_batch, id, tf);
           const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
           sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-          if (flags & 0x1000u) r0 = tf.q0.x + tf.q5.w + (float)tf.batch, r1 = tf.q3.y + tf.q2.x + tf.q1.x, r2 = tf.q4.z + (float)sd.tw;
+          const int px = tx0 + (int)(p & 31), py = ty0 + (int)(p >> 5);
+          M m;
+          if (flags & 0x1000u)
+            r0 = tf.q0.x + tf.q5.w + (float)tf.batch, r1 = tf.q3.y + tf.q2.x + tf.q1.x, r2 = tf.q4.z + (float)sd.tw;
+          else if (isV)
+            shade_pixel_v(m, K, sd, tf, px, py, s_zv[p], r0, r1, r2);
           else
-          shade_pixel_v(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
-          }
-          s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
-          if (STATS)
-            n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
+            shade_pixel_s(m, K, sd, tf, px, py, s_zv[p], r0, r1, r2);
+          if constexpr (std::is_same<M, FastMath>::value) bad |= m.bad;
         }
-      } else {
-        const uint32_t i = (c - cV) * 64 + lane;
-        if (i < nS) {
-          const uint32_t p = s_list[TILE * TILE - 1 - i];
-          const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
-          TriFetch tf;
-          fetch_tri(tris, tri_batch, id, tf);
-          const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-          ShadeDesc sd;
-          sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-          float r0, r1, r2;
-          shade_pixel_s(K, sd, tf, tx0 + (int)(p & 31), ty0 + (int)(p >> 5), s_zv[p], r0, r1, r2);
-          s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
-          if (STATS)
-            n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
-        }
+        s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
+        if (STATS && count)
+          n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
       }
-    }
+      return bad;
+    };
+    auto dense_passes = [&](auto policy, bool count) -> bool {
+      const bool bv = class_pass(policy, std::true_type{}, count);
+      const bool bs = class_pass(policy, std::false_type{}, count);
+      return bv | bs;
+    };
+    const bool bad = dense_passes(FastMath{}, true);
+    if (__ballot(bad) != 0ull && lane == 0) s_cnt[2] = 1u;
     __syncthreads();
+    if (s_cnt[2]) { // workgroup-uniform
+      if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
+      dense_passes(IeeeMath{}, false);
+      __syncthreads();
+    }
 
     // ---- 3. coalesced write-out of the three colour planes ----------------------------------------------------------
     C0 = *reinterpret_cast<const float4 *>(&s_c[0][p0]);

@@ -165,6 +165,27 @@ def test_degenerate_offscreen_and_nonfinite_triangles(ctx, orc):
         compare(gpu, ref, "degenerate")
 
 
+@pytest.mark.parametrize("shader", [abi.SHADER_PHONG, abi.SHADER_TEXTURE, abi.SHADER_NORMAL])
+def test_operands_outside_the_fast_math_range(ctx, orc, shader):
+    """k_shade's optimistic short rcp/sqrt sequences must hand over to the IEEE expansions: zero / huge / tiny normals
+    (sqrt of 0, of +inf, of a denormal), a light straight above a pixel (1/sqrt(0)) and a light at the eye."""
+    tris = np.concatenate([
+        ccw((4, 4), (30.5, 4), (4, 30.5), nrm=(0, 0, 0)),                                   # |n| = 0
+        ccw((34, 4), (60.5, 4), (34, 30.5), nrm=(1e30, -1e30, 1e30)),                       # |n|^2 overflows
+        ccw((4, 34), (30.5, 34), (4, 60.5), nrm=(1e-30, 1e-30, -1e-30)),                    # |n|^2 underflows
+        ccw((34, 34), (47.5, 34), (34, 47.5), nrm=(0.3, -0.2, -1)),                         # ordinary, V + S columns
+        ccw((50, 50), (55, 50), (50, 55), nrm=(0, 0, -1), uv=((0.1, 0.1), (0.9, 0.2), (0.4, 0.8)))])  # S columns only
+    lights = [[(40.0, 40.0, 60.0), (500, 500, 500)],   # x, y = a pixel corner of the fourth triangle: lx = ly = 0
+              [(0.0, 0.0, 1.0), (300, 200, 100)]]      # at the eye
+    f = frame(tris, shader=shader, lights=lights, tex=scenes.TEX_SPOT if shader == abi.SHADER_TEXTURE else -1)
+    gpu, ref = run_both(ctx, orc, f)
+    compare(gpu, ref, f"fast-math fallback, shader {shader}")
+    assert ctx.debug_counters()[11] >= 1, "no tile took the IEEE pass: the test does not exercise the fallback"
+    f = frame(tris, shader=shader, lights=lights, tex=scenes.TEX_SPOT if shader == abi.SHADER_TEXTURE else -1, flags=abi.FUSED_CLEAR | abi.UNIFIED)
+    gpu, ref = run_both(ctx, orc, f)
+    compare(gpu, ref, f"fast-math fallback (unified), shader {shader}")
+
+
 def test_z_ties_v_first_wins_s_last_wins(ctx, orc):
     a = ccw((8, 8), (28.5, 8), (8, 28.5))
     b = a.copy()
