@@ -222,6 +222,9 @@ int srz_sync(srz_ctx *ctx);
 /* self-check of the device arithmetic: compares the kernels' short exact reciprocal / square-root sequences with the
  * IEEE expansions on all 2^32 binary32 operands. out4 = {operands on the fast path, rcp, sqrt, 1/sqrt mismatches} */
 int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4);
+/* Same for the division-by-reciprocal sequence of the scalar-tail shaders (texel / 255, intensity / distance):
+ * out3 = { pairs tested, mismatches vs a / b on pseudo-random in-range pairs, mismatches of texel / 255 for texel 0..255 }. */
+int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
 /* diagnostic only: arm!=0 allocates a per-tile timeline filled by the next srz_frameset_stats; arm==0 copies it out

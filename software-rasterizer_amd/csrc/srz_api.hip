@@ -820,6 +820,18 @@ int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4) {
   return SRZ_OK;
 }
 
+int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3) {
+  if (!ctx || !out3) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  launch_verify_fastdiv(ctx->d_stats, ctx->stream);
+  unsigned long long h[3];
+  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3; ++i) out3[i] = h[i];
+  return SRZ_OK;
+}
+
 /* diagnostic: per-tile {start,end (100 MHz wall clock), HW_ID, blocks} of the next stats run; cap = tiles */
 int srz_debug_timeline(srz_ctx *ctx, uint64_t *out, size_t n_tiles, int arm) {
   if (!ctx) return SRZ_E_INVALID;

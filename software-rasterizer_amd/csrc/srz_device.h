@@ -117,6 +117,7 @@ void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s);
 void launch_verify_fastmath(unsigned long long *d_out4, hipStream_t s);
+void launch_verify_fastdiv(unsigned long long *d_out3, hipStream_t s);
 void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s);
 
 } // namespace srz

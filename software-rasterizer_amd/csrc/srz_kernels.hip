@@ -62,8 +62,8 @@ __device__ __forceinline__ float rcp_core(float x) { // v_rcp_f32 + one Newton s
   float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
-__device__ __forceinline__ float sqrt_core(float x) { // v_sqrt_f32 corrected by the exact residual
-  float s = __builtin_amdgcn_sqrtf(x), h = 0.5f * __builtin_amdgcn_rsqf(x);
+__device__ __forceinline__ float sqrt_core(float x) { // x * v_rsq_f32(x) corrected by the exact residual
+  float r = __builtin_amdgcn_rsqf(x), s = x * r, h = 0.5f * r; // (one transcendental: they issue at ~0.57x the FMA rate)
   return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
 }
 // The slow (full IEEE) variants are out-of-line and entered only when SOME lane of the wave has an out-of-range
@@ -94,18 +94,43 @@ __device__ __forceinline__ float rsqrt2_rn(float d) {
 //   IeeeMath    the compiler's full IEEE expansions.
 // All three return identical bits wherever FastMath's checks pass (tests/test_gpu_fastmath.py).
 __device__ __forceinline__ bool fast_pos(float x) { return ((f2u_(x) >> 23) - 27u) <= 200u; } // fast_range and x > 0
+// a / b from y = RN(1/b) (Markstein): q0 = a*y is refined twice with the exact residual a - b*q.  With y correctly rounded
+// and q1 within one ulp, RN(q1 + r*y) is the correctly rounded quotient, i.e. exactly what the IEEE division returns,
+// PROVIDED nothing under- or overflows on the way: callers guarantee 2^-40 <= |b| <= 2^40 and a == +0 or
+// 2^-60 <= |a| <= 2^60 (a -0 numerator would come out as +0).  Checked on device against a / b in tests/test_gpu_fastmath.py.
+__device__ __forceinline__ float div_by_rcp(float a, float b, float y) {
+  float q = a * y;
+  q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+}
+__device__ __forceinline__ bool div_num_ok(float a) { // (int |, &: no short-circuit branches)
+  return ((int)(f2u_(a) == 0u) | (int)((((f2u_(a) >> 23) & 0xffu) - 67u) <= 120u)) != 0;
+}
+__device__ __forceinline__ bool div_den_ok(float b) { return ((f2u_(b) >> 23) - 87u) <= 80u; } // 2^-40 <= b <= 2^40, b > 0
 struct BranchMath {
   __device__ __forceinline__ float rcp(float x) { return rcp_rn(x); }
   __device__ __forceinline__ float sqrt(float x) { return sqrt_rn(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return rsqrt2_rn(d); }
 };
 struct IeeeMath {
+  __device__ __forceinline__ float div255(float a) { return a / 255.0f; }
+  __device__ __forceinline__ void div3(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2) {
+    q0 = a0 / b, q1 = a1 / b, q2 = a2 / b;
+  }
   __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
   __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
 };
 struct FastMath {
   bool bad = false;
+  // texel / 255.0f for texel = 0..255: numerator and divisor are always inside div_by_rcp's range
+  __device__ __forceinline__ float div255(float a) { return div_by_rcp(a, 255.0f, __builtin_bit_cast(float, 0x3b808081u)); }
+  // three numerators (wave-uniform light intensities) over one positive per-pixel divisor: one reciprocal
+  __device__ __forceinline__ void div3(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2) {
+    bad |= ((int)div_den_ok(b) & (int)div_num_ok(a0) & (int)div_num_ok(a1) & (int)div_num_ok(a2)) == 0;
+    const float y = rcp_core(b);
+    q0 = div_by_rcp(a0, b, y), q1 = div_by_rcp(a1, b, y), q2 = div_by_rcp(a2, b, y);
+  }
   __device__ __forceinline__ float rcp(float x) {
     bad |= !fast_range(x);
     return rcp_core(x);
@@ -493,7 +518,8 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
 }
 
 // TextureLoader::getTextureColor(vec2) (src/TextureLoader.cpp:14-31)
-__device__ __forceinline__ void s_texel(const ShadeDesc &sd, float u, float v, float &o0, float &o1, float &o2) {
+template <class M>
+__device__ __forceinline__ void s_texel(M &m, const ShadeDesc &sd, float u, float v, float &o0, float &o1, float &o2) {
   float cu = std_clamp(u, 0.0f, 1.0f), cv = std_clamp(v, 0.0f, 1.0f);
   float fx = cu * (float)sd.tw, fy = cv * (float)sd.th;
   int x = (int)fx, y = (int)fy;
@@ -502,8 +528,8 @@ __device__ __forceinline__ void s_texel(const ShadeDesc &sd, float u, float v, f
     return;
   }
   uint32_t texel = sd.tex[(size_t)y * sd.tw + x];
-  o0 = (float)(texel & 0xffu) / 255.0f, o1 = (float)((texel >> 8) & 0xffu) / 255.0f,
-  o2 = (float)((texel >> 16) & 0xffu) / 255.0f;
+  o0 = m.div255((float)(texel & 0xffu)), o1 = m.div255((float)((texel >> 8) & 0xffu)),
+  o2 = m.div255((float)((texel >> 16) & 0xffu));
 }
 
 // Shader::BlinnPhong scalar (src/Shader.cpp:510-543); the two std::pow(x,2) and the sqrt are binary64 there
@@ -516,7 +542,8 @@ __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, f
   float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
   double dx = (double)(Lx - px), dy = (double)(Ly - py);
   float dsq = (float)__builtin_sqrt(dx * dx + dy * dy);
-  float d0 = I0 / dsq, d1 = I1 / dsq, d2 = I2 / dsq;
+  float d0, d1, d2;
+  m.div3(I0, I1, I2, dsq, d0, d1, d2);
   float nlx = ldx, nly = ldy, nlz = ldz;
   normalize3(m, nlx, nly, nlz);
   float cosTheta = std_max(0.0f, dot3(nx, ny, nz, nlx, nly, nlz));
@@ -538,10 +565,10 @@ __device__ __forceinline__ void s_bump_common(M &m, const ShadeDesc &sd, float n
   float t0 = (nx * ny) / sq, t1 = sq, t2 = (nz * ny) / sq;
   float b0 = ny * t2 - t1 * nz, b1 = nz * t0 - t2 * nx, b2 = nx * t1 - t0 * ny;
   float a0, a1, a2, u0, u1, u2, w0, w1, w2;
-  s_texel(sd, u, v, a0, a1, a2);
+  s_texel(m, sd, u, v, a0, a1, a2);
   float on = __builtin_sqrtf(dot3(a0, a1, a2, a0, a1, a2));
-  s_texel(sd, (u + 1.0f) / (float)sd.tw, v, u0, u1, u2);
-  s_texel(sd, u, (v + 1.0f) / (float)sd.th, w0, w1, w2);
+  s_texel(m, sd, (u + 1.0f) / (float)sd.tw, v, u0, u1, u2);
+  s_texel(m, sd, u, (v + 1.0f) / (float)sd.th, w0, w1, w2);
   float dU = kh * kn * (__builtin_sqrtf(dot3(u0, u1, u2, u0, u1, u2)) - on);
   float dV = kh * kn * (__builtin_sqrtf(dot3(w0, w1, w2, w0, w1, w2)) - on);
   float l0 = -dU, l1 = -dV, l2 = 1.0f;
@@ -561,7 +588,7 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
   } else if (sd.shader >= SRZ_SHADER_TEXTURE && sd.shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
     float sx = px, sy = py, sz = pz, snx = nx, sny = ny, snz = nz;
-    if (sd.shader != SRZ_SHADER_PHONG) s_texel(sd, u, v, kd0, kd1, kd2);
+    if (sd.shader != SRZ_SHADER_PHONG) s_texel(m, sd, u, v, kd0, kd1, kd2);
     if (sd.shader == SRZ_SHADER_BUMP) {
       float on;
       s_bump_common(m, sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
@@ -654,7 +681,7 @@ __global__ void probe_v(RenderArgs a, float *o) {
   K.eye[0] = fd->eye[0], K.eye[1] = fd->eye[1], K.eye[2] = fd->eye[2];
   K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
   K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
-  K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
+  K.p = 150.0f, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = 2; // constants: the static count is the dynamic path
   K.lights = as_const(a.lights);
   TriFetch tf;
   fetch_tri(as_const(a.tris), as_const(a.tri_batch), threadIdx.x, tf);
@@ -1273,6 +1300,42 @@ __global__ void k_verify_fastmath(unsigned long long *out) {
 }
 void launch_verify_fastmath(unsigned long long *d_out, hipStream_t s) {
   hipLaunchKernelGGL(k_verify_fastmath, dim3(8192), dim3(256), 0, s, d_out);
+}
+
+// Companion check of div_by_rcp against the IEEE division: out[0] = pairs tested, out[1] = mismatches on pseudo-random
+// (a, b) inside the documented ranges (uniform exponents, random mantissas, plus few-significant-bit operands whose
+// quotients are exact or near-exact), out[2] = mismatches of texel / 255 over all 256 texels (must both be 0).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull, z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull, z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ void k_verify_fastdiv(unsigned long long *out, uint32_t per_thread) {
+  unsigned long long bad = 0, bad255 = 0, n = 0;
+  uint64_t st = mix64(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x);
+  for (uint32_t i = 0; i < per_thread; ++i) {
+    st = mix64(st);
+    uint32_t ua = (uint32_t)st, ub = (uint32_t)(st >> 32);
+    const uint32_t ea = 67u + ((ua >> 23) & 0xffu) % 121u, eb = 87u + ((ub >> 23) & 0xffu) % 81u;
+    if (i & 1u) ua &= ~0x7ff000u, ub &= ~0x7fff00u; // few significant bits
+    ua = (ua & 0x807fffffu) | (ea << 23), ub = (ub & 0x007fffffu) | (eb << 23);
+    const float a = __builtin_bit_cast(float, ua), b = __builtin_bit_cast(float, ub);
+    bad += !(div_num_ok(a) && div_den_ok(b)) || f2u_(div_by_rcp(a, b, rcp_core(b))) != f2u_(a / b);
+    ++n;
+  }
+  if (blockIdx.x == 0) {
+    FastMath fm;
+    const float t = (float)threadIdx.x;
+    bad255 += f2u_(fm.div255(t)) != f2u_(t / 255.0f);
+    float q0, q1, q2;
+    fm.div3(0.0f, t, 1.0f, 255.0f, q0, q1, q2); // +0 numerator stays +0
+    bad255 += f2u_(q0) != 0u || f2u_(q1) != f2u_(t / 255.0f) || fm.bad;
+  }
+  atomicAdd(&out[0], n);
+  if (bad) atomicAdd(&out[1], bad);
+  if (bad255) atomicAdd(&out[2], bad255);
+}
+void launch_verify_fastdiv(unsigned long long *d_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_verify_fastdiv, dim3(8192), dim3(256), 0, s, d_out, 2048u);
 }
 
 // BGR u8 (row_stride bytes per row) → one dword per texel

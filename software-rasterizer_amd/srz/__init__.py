@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath"]
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath", "srz_verify_fastdiv"]
 
 
 class SrzError(RuntimeError):
@@ -62,6 +62,7 @@ def lib():
         L.srz_sync.argtypes = [vp]
         L.srz_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.srz_verify_fastmath.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.srz_verify_fastdiv.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_debug_timeline.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_int]
         _lib = L
     return _lib
@@ -179,6 +180,11 @@ class Context:
     def verify_fastmath(self):
         out = (C.c_uint64 * 4)()
         self._check(lib().srz_verify_fastmath(self.h, out))
+        return [int(x) for x in out]
+
+    def verify_fastdiv(self):
+        out = (C.c_uint64 * 3)()
+        self._check(lib().srz_verify_fastdiv(self.h, out))
         return [int(x) for x in out]
 
     def debug_timeline(self, n_tiles, arm):
