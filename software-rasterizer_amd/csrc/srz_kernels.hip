@@ -1065,8 +1065,9 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
   }
 }
 
+// k_shade is latency-sensitive: measurably slower at 3 waves per SIMD than at 4 — hold the allocator to 128 VGPRs
 #ifndef SRZ_SHADE_MINW
-#define SRZ_SHADE_MINW 1
+#define SRZ_SHADE_MINW 4
 #endif
 template <bool STATS>
 __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
@@ -1074,7 +1075,8 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_zv[TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];
-  __shared__ uint32_t s_cnt[3]; // V count, S count, "some operand left FastMath's range"
+  __shared__ uint32_t s_wcnt[4][2]; // per wave: V-class and S-class pixels among its 256
+  __shared__ uint32_t s_flag;       // "some operand left FastMath's range"
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1116,7 +1118,6 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
     const uint32_t *gv = vis0 + (size_t)ly * W + x4;
     float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), C0 = z4, C1 = z4, C2 = z4;
     uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
-    if (tid == 0) s_cnt[0] = 0, s_cnt[1] = 0, s_cnt[2] = 0;
     if (full) {
       z4 = *reinterpret_cast<const float4 *>(gz);
       id4 = *reinterpret_cast<const uint4 *>(gv);
@@ -1141,24 +1142,38 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
     *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
     *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
-    __syncthreads(); // s_cnt zeroed
+    // classify this thread's 4 pixels; per-wave class counts go through LDS (no atomics: a wave's first slot in each list
+    // is the sum of the counts of the waves before it)
+    unsigned long long mv[4], ms[4];
+    uint32_t cv = 0, cs = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t id = k == 0 ? id4.x : k == 1 ? id4.y : k == 2 ? id4.z : id4.w;
-      const bool own = id != NO_TRI, isS = own && (id & S_CLASS_BIT) != 0, isV = own && !isS;
-      const unsigned long long mv = __ballot(isV), ms = __ballot(isS);
+      const bool own = id != NO_TRI, isS = own && (id & S_CLASS_BIT) != 0;
+      mv[k] = __ballot(own && !isS), ms[k] = __ballot(isS);
+      cv += (uint32_t)__popcll(mv[k]), cs += (uint32_t)__popcll(ms[k]);
+    }
+    if (lane == 0) s_wcnt[wave][0] = cv, s_wcnt[wave][1] = cs;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    uint32_t bV = 0, bS = 0, nV = 0, nS = 0; // this wave's first slot in each list, list lengths (all wave-uniform)
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const uint32_t v = s_wcnt[w2][0], sN = s_wcnt[w2][1];
+      bV += w2 < wave ? v : 0u, bS += w2 < wave ? sN : 0u, nV += v, nS += sN;
+    }
+    bV = (uint32_t)__builtin_amdgcn_readfirstlane((int)bV), bS = (uint32_t)__builtin_amdgcn_readfirstlane((int)bS);
+    nV = (uint32_t)__builtin_amdgcn_readfirstlane((int)nV), nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)nS);
+    {
       const unsigned long long lt = (1ull << lane) - 1ull;
-      uint32_t bv = 0, bs = 0;
-      if (lane == 0) {
-        if (mv) bv = atomicAdd(&s_cnt[0], (uint32_t)__popcll(mv));
-        if (ms) bs = atomicAdd(&s_cnt[1], (uint32_t)__popcll(ms));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((mv[k] >> lane) & 1ull) s_list[bV + __popcll(mv[k] & lt)] = (uint16_t)(p0 + k);
+        if ((ms[k] >> lane) & 1ull) s_list[TILE * TILE - 1 - (bS + __popcll(ms[k] & lt))] = (uint16_t)(p0 + k);
+        bV += (uint32_t)__popcll(mv[k]), bS += (uint32_t)__popcll(ms[k]);
       }
-      bv = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv), bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
-      if (isV) s_list[bv + __popcll(mv & lt)] = (uint16_t)(p0 + k);
-      if (isS) s_list[TILE * TILE - 1 - (bs + __popcll(ms & lt))] = (uint16_t)(p0 + k);
     }
     __syncthreads();
-    const uint32_t nV = s_cnt[0], nS = s_cnt[1];
 
     // ---- 2. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
@@ -1206,9 +1221,9 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
       return bv | bs;
     };
     const bool bad = dense_passes(FastMath{}, true);
-    if (__ballot(bad) != 0ull && lane == 0) s_cnt[2] = 1u;
+    if (__ballot(bad) != 0ull && lane == 0) s_flag = 1u;
     __syncthreads();
-    if (s_cnt[2]) { // workgroup-uniform
+    if (s_flag) { // workgroup-uniform
       if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
       dense_passes(IeeeMath{}, false);
       __syncthreads();
