@@ -71,8 +71,7 @@ struct srz_frameset {
   RasterRec *d_band_recs = nullptr;
   uint32_t *d_band_count = nullptr;
   uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_tile_mask = nullptr;
-  uint8_t *d_tile_state = nullptr;
-  uint32_t mask_words = 0, state_stride = 0;
+  uint32_t mask_words = 0;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
   std::vector<DrawDesc> h_draws;
@@ -122,7 +121,6 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_worklist);
   (void)hipFree(fs->d_work_count);
   (void)hipFree(fs->d_tile_mask);
-  (void)hipFree(fs->d_tile_state);
   (void)hipFree(fs->d_sdesc);
   (void)hipFree(fs->d_draws);
   (void)hipFree(fs->d_band_count);
@@ -144,8 +142,11 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.work_count = fs->d_work_count;
   a.tile_mask = fs->d_tile_mask;
   a.mask_words = fs->mask_words;
-  a.tile_state = fs->d_tile_state;
-  a.state_stride = fs->state_stride;
+  // k_shade lanes per frame: >= 128 (one or two tiles per virtual workgroup at 1024^2), and at least 4 virtual
+  // workgroups per physical one when the batch has few frames
+  static const uint32_t split = getenv("SRZ_SHADE_SPLIT") ? (uint32_t)atoi(getenv("SRZ_SHADE_SPLIT")) : 0u;
+  const uint32_t grid = fs->max_tiles < 4096u ? fs->max_tiles : 4096u, fpad = fs->n_frames < 8 ? (uint32_t)fs->n_frames : ((uint32_t)fs->n_frames + 7u) / 8u * 8u;
+  a.shade_split = split ? split : std::max(128u, 4u * grid / std::max(fpad, 1u));
   a.tiles_x = fs->tiles_x;
   a.n_local_bands = fs->n_local_bands;
   a.n_frames = (uint32_t)fs->n_frames;
@@ -221,7 +222,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipEventRecord(ep.t0, s));
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
-  HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t), s));
+  if (fs->max_tris == 0) HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * fs->n_frames, s)); // (else: k_setup)
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
   launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, fs->max_tris, s);
@@ -244,7 +245,6 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     launch_clear(a, fs->max_tiles, false, s);
   }
   launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
-  launch_lists(a, fs->n_frames, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, s);
   if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
@@ -451,12 +451,9 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_band_recs, sizeof(RasterRec) * list_off));
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
   FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
-  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t)));
+  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * n_frames));
   fs->mask_words = (fs->tiles_x + 31u) / 32u;
   FS_TRY(dev_alloc((void **)&fs->d_tile_mask, sizeof(uint32_t) * (size_t)n_frames * fs->n_local_bands * fs->mask_words));
-  fs->state_stride = (fs->n_local_bands * fs->tiles_x + 15u) & ~15u;
-  FS_TRY(dev_alloc((void **)&fs->d_tile_state, (size_t)n_frames * fs->state_stride));
-  FS_TRY(hipMemset(fs->d_tile_state, 0, (size_t)n_frames * fs->state_stride));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_band_count, sizeof(uint32_t) * count_off));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));

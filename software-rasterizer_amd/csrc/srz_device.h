@@ -90,12 +90,11 @@ struct RenderArgs {
   const RasterRec *band_recs;
   const uint32_t *band_count;
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
-  uint32_t *worklist;            // tiles that need shading: (frame*n_local_bands + lb)*tiles_x + tx
-  uint32_t *work_count;
-  uint8_t *tile_state;           // [frame][state_stride] one byte per tile, written by k_raster: 1 = owned, else 0
-  uint32_t state_stride;         // tiles per frame rounded up to 16 (padding stays 0)
+  uint32_t *worklist;            // [frame][tiles per frame]: tiles (lb*tiles_x + tx) that have an owner, in arrival order
+  uint32_t *work_count;          // [frame] entries in the frame's list (zeroed by k_setup, bumped by k_raster)
   uint32_t *tile_mask;           // [frame][local band][mask_words]: bit tx set = some bbox of the band list overlaps tile tx
   uint32_t mask_words;           // (tiles_x + 31) / 32
+  uint32_t shade_split;          // k_shade: virtual workgroups ("lanes") per frame
   uint32_t tiles_x, n_local_bands, n_frames;
   float *out;             // [frame][4][local_rows][width]
   uint64_t frame_stride;  // floats per frame in out = 4*local_rows*width
@@ -111,7 +110,6 @@ void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool sta
 void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
                   uint32_t max_tris, hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s);
-void launch_lists(const RenderArgs &a, int n_frames, hipStream_t s);
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,

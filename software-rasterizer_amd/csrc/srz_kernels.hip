@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.work_count[blockIdx.y] = 0u; // this frame's work list starts empty
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
   const int W = fd->width, H = fd->height;
   const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
@@ -745,10 +746,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   {  // no bbox of the band list reaches this tile: nothing to rasterise, and its clear (if any) is k_clear's job
     const uint32_t txi = (uint32_t)tx0 / TILE;
     const uint32_t word = as_const(a.tile_mask)[((size_t)frame * a.n_local_bands + lb) * a.mask_words + (txi >> 5)];
-    if (!((word >> (txi & 31u)) & 1u)) {
-      if (lane == 0) a.tile_state[(size_t)frame * a.state_stride + tile] = 0;
-      return;
-    }
+    if (!((word >> (txi & 31u)) & 1u)) return;
   }
   float *zl = s_z[wave];
   uint32_t *il = s_id[wave];
@@ -957,8 +955,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
       }
     }
   }
-  // (no worklist append here: 10^5 tiles bumping one counter serialise at ~10 ns each; k_lists compacts the states)
-  if (lane == 0) a.tile_state[(size_t)frame * a.state_stride + tile] = tile_has_owner ? 1 : 0;
+  // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
+  if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame], 1u)] = tile;
   if (a.timeline && lane == 0) { // diagnostic: per-tile residency (srz_debug_timeline)
     unsigned hw = 0;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -990,39 +988,6 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
 // the back), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
 // colours go to LDS planes and leave as coalesced 16-byte stores.
 // ================================================================================================================
-// ================================================================================================================
-// k_lists — one WAVE per frame turns k_raster's per-tile states (one byte per tile, rows padded to 16) into the dense
-// worklist k_shade walks: 16 states per lane in one load, wave prefix sum, ONE atomic per 1024 tiles, fill.
-// ================================================================================================================
-__global__ __launch_bounds__(64) void k_lists(RenderArgs a) {
-  const uint32_t f = blockIdx.x, tpf = a.n_local_bands * a.tiles_x;
-  const int lane = threadIdx.x;
-  const SRZ_CAS uint8_t *st = as_const(a.tile_state) + (size_t)f * a.state_stride;
-  for (uint32_t t0 = 0; t0 < tpf; t0 += 1024) {
-    const uint32_t t = t0 + (uint32_t)lane * 16u;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    if (t < tpf) { // (padding bytes are zero)
-      const u32x4 q = *reinterpret_cast<const SRZ_CAS u32x4 *>(st + t);
-      w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
-    }
-    const uint32_t n = (uint32_t)(__popc(w[0] & 0x01010101u) + __popc(w[1] & 0x01010101u) + __popc(w[2] & 0x01010101u) +
-                                  __popc(w[3] & 0x01010101u));
-    uint32_t incl = n;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o);
-      if (lane >= o) incl += up;
-    }
-    const uint32_t total = __shfl(incl, 63);
-    if (total == 0) continue;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(a.work_count, total);
-    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - n;
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if ((w[k >> 2] >> ((k & 3) * 8)) & 1u) a.worklist[pos++] = f * tpf + t + (uint32_t)k;
-  }
-}
-
 // The clear of one tile nobody owns (z = +inf, colour 0; src/Render.cpp:46-55 restricted to the tile): pure 16-byte
 // streaming stores, issued by k_shade between two shaded tiles so that they drain under the shading arithmetic.
 __device__ __forceinline__ void clear_tile(const RenderArgs &a, uint32_t e, int tid) {
@@ -1080,12 +1045,22 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t n_work = as_const(a.work_count)[0];
   unsigned long long n_vis = 0, n_vis_tex = 0;
-  for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
-    const uint32_t e = as_const(a.worklist)[w];
-    const uint32_t tx = e % a.tiles_x, rest = e / a.tiles_x;
-    const uint32_t lb = rest % a.n_local_bands, f = rest / a.n_local_bands;
+  // The persistent grid walks VIRTUAL workgroups v = (group of 8 frames, lane j, frame within the group): v shades every
+  // S-th entry of its frame's work list from entry j.  Frame-in-group is the fastest index, so physical workgroup b
+  // (on XCD b % 8) shades frame f with f % 8 == b % 8 — the XCD that rasterised it, whose L2 holds its z / owner ids —
+  // and the ~1000 resident workgroups cover only a group or two of frames at a time (triangles + ids stay L2-resident;
+  // dealing v over ALL frames at once thrashes L2: +10 % kernel time; dropping the XCD affinity: +5..12 %).
+  const uint32_t F = a.n_frames, tpf = a.n_local_bands * a.tiles_x, S = a.shade_split;
+  const uint32_t gsz = F < 8u ? F : 8u; // (fewer than 8 frames: every XCD works on all of them)
+  const uint32_t n_virtual = ((F + gsz - 1u) / gsz) * gsz * S;
+  for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+  const uint32_t r = v % (gsz * S), f = (v / (gsz * S)) * gsz + r % gsz, j = r / gsz;
+  if (f >= F) continue;
+  const uint32_t n_work = as_const(a.work_count)[f];
+  for (uint32_t w = j; w < n_work; w += S) {
+    const uint32_t e = as_const(a.worklist)[(size_t)f * tpf + w];
+    const uint32_t tx = e % a.tiles_x, lb = e / a.tiles_x;
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
     const int W = fd->width, H = fd->height;
     const uint32_t tri_off = fd->tri_off, batch_off = fd->batch_off;
@@ -1245,6 +1220,7 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
     }
     __syncthreads(); // LDS is reused by the next tile of this persistent workgroup
   }
+  }
   if (STATS) {
     for (int o = 32; o > 0; o >>= 1) {
       n_vis += __shfl_down(n_vis, o);
@@ -1390,10 +1366,6 @@ void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_coun
   const int waves = n_chunks <= 256 ? 4 : (n_chunks <= 1024 ? 8 : BANDS_MAX_WAVES);
   const size_t lds = sizeof(uint32_t) * (3u * (size_t)cap + 256u * waves + 2u + a.mask_words);
   hipLaunchKernelGGL(k_bands, grid, dim3(64 * waves), lds, s, a, band_recs, band_count, cap);
-}
-
-void launch_lists(const RenderArgs &a, int n_frames, hipStream_t s) {
-  if (n_frames > 0 && a.n_local_bands) hipLaunchKernelGGL(k_lists, dim3((uint32_t)n_frames), dim3(64), 0, s, a);
 }
 
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s) {
