@@ -198,7 +198,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
-                         "kernel": "hot path = k_setup + k_bands + k_raster + k_shade (one launch each per step)",
+                         "kernel": "hot path = k_setup + k_bands + k_raster + k_shade in line, k_clear beside k_raster/k_shade on a second stream (one launch each per step)",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "launch_ms": kt["total_ms"], "k_setup_bands_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"],
                          "k_shade_ms": kt["shade_ms"], "launches_timed": kt["launches"],

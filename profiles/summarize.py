@@ -16,13 +16,13 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(os.path.dirname(here), "gpurun_out", f"prof_{tag}")
-KERNELS = ("k_setup", "k_bands", "k_raster", "k_shade")
+KERNELS = ("k_setup", "k_bands", "k_raster", "k_clear", "k_shade")
 
 
 def one(pattern):
     g = glob.glob(os.path.join(src, pattern), recursive=True)
     assert g, pattern
-    return g[0]
+    return max(g, key=os.path.getmtime)  # (gpurun merges runs into the same scratch directory: take the latest)
 
 
 shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_stats.csv"))
@@ -46,7 +46,8 @@ def pmc(dirname):
 
 fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
-out = {"tag": tag, "bench_line": bench, "avg_kernel_us": per_kernel_us, "pipeline_us_sum": sum(per_kernel_us.values()),
+out = {"tag": tag, "bench_line": bench, "avg_kernel_us": per_kernel_us, "pipeline_us_sum": sum(v for k, v in per_kernel_us.items() if k != "k_clear"),
+       "note": "k_clear runs on a second stream beside k_raster/k_shade: its time overlaps theirs and is not in pipeline_us_sum",
        "pmc_avg_per_launch": {}, "units": "FETCH_SIZE/WRITE_SIZE in KiB (rocprofv3); bytes below = KiB*1024"}
 tot_w = tot_f = 0.0
 for k in KERNELS:
