@@ -44,7 +44,9 @@ struct srz_ctx {
   unsigned long long *d_timeline = nullptr; // diagnostic buffer (srz_debug_timeline)
   size_t timeline_cap = 0;
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
+  hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
+  unsigned ev_next = 0;
 };
 
 struct srz_target {
@@ -231,23 +233,27 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
   const bool side = any_fused && fs->max_tiles >= 8192;
+  unsigned ev = 0;
   if (side) {
     if (!ctx->stream2) {
       HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      for (int i = 0; i < srz_ctx::EV_RING; ++i) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+      }
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    ev = ctx->ev_next++ % srz_ctx::EV_RING;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[ev], s));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork[ev], 0));
     launch_clear(a, fs->max_tiles, true, ctx->stream2);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], ctx->stream2));
   } else if (any_fused) {
     launch_clear(a, fs->max_tiles, false, s);
   }
   launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, s);
-  if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+  if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -319,7 +325,11 @@ void srz_destroy(srz_ctx *ctx) {
   for (int i = 0; i < MAX_MESH; ++i) (void)hipFree(ctx->mesh[i].d_verts), (void)hipFree(ctx->mesh[i].d_faces);
   (void)hipFree(ctx->d_tex);
   (void)hipFree(ctx->d_stats);
-  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2), (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->stream2) {
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream2);
+    for (int i = 0; i < srz_ctx::EV_RING; ++i) (void)hipEventDestroy(ctx->ev_fork[i]), (void)hipEventDestroy(ctx->ev_join[i]);
+  }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
