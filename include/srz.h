@@ -194,7 +194,9 @@ int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_pl
                           void *stream);
 /* Re-upload the per-frame data of a sceneset (matrices, eye, lights, shader constants, flags, shader/texture per draw)
  * without re-allocating anything.  The structure must be unchanged: same frame count and size, same mesh slots and face
- * counts per draw, same light counts; otherwise SRZ_E_INVALID (create a new set). */
+ * counts per draw, same light counts; otherwise SRZ_E_INVALID (create a new set).  The upload is ONE asynchronous copy
+ * on the context's own stream (ordered against srz_target_draw / renders submitted there, no host synchronisation);
+ * renders of this set submitted on a caller-provided stream must be ordered against it by the caller. */
 int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *frames, int n_frames);
 
 /* ---- device-resident framebuffer = RenderingPipeline's m_zBuffer + m_channels kept in HBM between calls ----------

@@ -76,6 +76,15 @@ struct srz_frameset {
   uint32_t mask_words = 0;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
+  // scenesets keep everything srz_sceneset_update rewrites in ONE device block [FrameDesc | lights | DrawDesc] that is
+  // refreshed by a single asynchronous copy from a small ring of pinned staging buffers (no stream sync per frame)
+  static constexpr int STAGE_RING = 4;
+  uint8_t *d_dyn = nullptr;
+  size_t dyn_bytes = 0, dyn_lights_off = 0, dyn_draws_off = 0;
+  uint8_t *h_stage[STAGE_RING] = {};
+  hipEvent_t stage_ev[STAGE_RING] = {};
+  bool stage_busy[STAGE_RING] = {};
+  unsigned stage_next = 0;
   std::vector<DrawDesc> h_draws;
   std::vector<int> h_draw_mesh;
   uint32_t n_draws = 0, max_faces = 0;
@@ -112,6 +121,14 @@ void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &
 }
 
 void free_frameset_buffers(srz_frameset *fs) {
+  for (int i = 0; i < srz_frameset::STAGE_RING; ++i) {
+    if (fs->h_stage[i]) (void)hipHostFree(fs->h_stage[i]);
+    if (fs->stage_ev[i]) (void)hipEventDestroy(fs->stage_ev[i]);
+  }
+  if (fs->d_dyn) { // d_frames / d_lights / d_draws point into the block
+    (void)hipFree(fs->d_dyn);
+    fs->d_frames = nullptr, fs->d_lights = nullptr, fs->d_draws = nullptr;
+  }
   (void)hipFree(fs->d_frames);
   (void)hipFree(fs->d_tris);
   (void)hipFree(fs->d_bbox);
@@ -560,12 +577,32 @@ int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frame
   }
   fs->n_draws = (uint32_t)h.size();
   fs->h_draws = h;
-  hipError_t e = hipMalloc(&fs->d_draws, sizeof(DrawDesc) * std::max<size_t>(h.size(), 1));
-  if (e == hipSuccess && !h.empty()) e = hipMemcpy(fs->d_draws, h.data(), sizeof(DrawDesc) * h.size(), hipMemcpyHostToDevice);
+  // one block for what srz_sceneset_update rewrites: [FrameDesc x n | lights | DrawDesc x draws], 16-byte aligned parts
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  fs->dyn_lights_off = up16(sizeof(FrameDesc) * (size_t)n_frames);
+  fs->dyn_draws_off = up16(fs->dyn_lights_off + sizeof(srz_light) * (size_t)fs->total_lights);
+  fs->dyn_bytes = up16(fs->dyn_draws_off + sizeof(DrawDesc) * std::max<size_t>(h.size(), 1));
+  uint8_t *blk = nullptr;
+  hipError_t e = hipMalloc(&blk, fs->dyn_bytes);
+  if (e == hipSuccess) e = hipMemcpy(blk, fs->d_frames, sizeof(FrameDesc) * (size_t)n_frames, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess && fs->total_lights)
+    e = hipMemcpy(blk + fs->dyn_lights_off, fs->d_lights, sizeof(srz_light) * (size_t)fs->total_lights, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess && !h.empty()) e = hipMemcpy(blk + fs->dyn_draws_off, h.data(), sizeof(DrawDesc) * h.size(), hipMemcpyHostToDevice);
+  for (int i = 0; e == hipSuccess && i < srz_frameset::STAGE_RING; ++i) {
+    e = hipHostMalloc((void **)&fs->h_stage[i], fs->dyn_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&fs->stage_ev[i], hipEventDisableTiming);
+  }
   if (e != hipSuccess) {
+    (void)hipFree(blk);
     srz_frameset_destroy(ctx, fs);
     return fail(ctx, SRZ_E_NOMEM, std::string("srz_sceneset_create: ") + hipGetErrorString(e));
   }
+  (void)hipFree(fs->d_frames);
+  (void)hipFree(fs->d_lights);
+  fs->d_dyn = blk;
+  fs->d_frames = reinterpret_cast<FrameDesc *>(blk);
+  fs->d_lights = reinterpret_cast<srz_light *>(blk + fs->dyn_lights_off);
+  fs->d_draws = reinterpret_cast<DrawDesc *>(blk + fs->dyn_draws_off);
   *out = fs;
   return SRZ_OK;
 }
@@ -600,11 +637,19 @@ int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *f
       if (b.shader != dr.shader || b.tex_id != dr.tex_id) b.shader = dr.shader, b.tex_id = dr.tex_id, batches_changed = true;
     }
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // descriptors may still be read by a render in flight
-  HIP_TRY(ctx, hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
-  if (!fs->h_draws.empty()) HIP_TRY(ctx, hipMemcpy(fs->d_draws, fs->h_draws.data(), sizeof(DrawDesc) * fs->h_draws.size(), hipMemcpyHostToDevice));
-  if (!h_lights.empty()) HIP_TRY(ctx, hipMemcpy(fs->d_lights, h_lights.data(), sizeof(srz_light) * h_lights.size(), hipMemcpyHostToDevice));
+  // one asynchronous copy on the context's stream: ordered after every render already submitted there (which may still
+  // be reading the descriptors) and before the next one.  Renders submitted on OTHER streams are the caller's to order.
+  const unsigned slot = fs->stage_next++ % srz_frameset::STAGE_RING;
+  if (fs->stage_busy[slot]) HIP_TRY(ctx, hipEventSynchronize(fs->stage_ev[slot])); // its copy of 4 updates ago
+  uint8_t *st = fs->h_stage[slot];
+  std::memcpy(st, fs->h_frames.data(), sizeof(FrameDesc) * (size_t)n_frames);
+  if (!h_lights.empty()) std::memcpy(st + fs->dyn_lights_off, h_lights.data(), sizeof(srz_light) * h_lights.size());
+  if (!fs->h_draws.empty()) std::memcpy(st + fs->dyn_draws_off, fs->h_draws.data(), sizeof(DrawDesc) * fs->h_draws.size());
+  HIP_TRY(ctx, hipMemcpyAsync(fs->d_dyn, st, fs->dyn_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(fs->stage_ev[slot], ctx->stream));
+  fs->stage_busy[slot] = true;
   if (batches_changed) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (rare: a draw switched shader or texture)
     HIP_TRY(ctx, hipMemcpy(fs->d_batches, fs->h_batches.data(), sizeof(BatchDesc) * fs->h_batches.size(), hipMemcpyHostToDevice));
     fs->sdesc_version = 0; // re-resolve batch → shader / texture at the next render
   }
