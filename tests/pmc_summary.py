@@ -1,0 +1,11 @@
+"""Dev tool: average per-launch PMC values per kernel from a rocprofv3 --pmc csv directory."""
+import collections, csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"]
+    if "<true>" in n: continue
+    for k in ("k_setup", "k_bands", "k_raster", "k_clear", "k_shade"):
+        if k in n: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k, {c: round(sum(v) / len(v) / 1e6, 2) for c, v in sorted(d.items())})
