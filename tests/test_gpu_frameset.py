@@ -103,8 +103,9 @@ def test_band_sharding_every_rank_on_one_gpu(orc, world, w, h):
         assert np.array_equal(bits(full[i]), bits(refs[i]))
 
 
-def test_full_size_properties_config2_batch():
-    """At BASELINE's full size with a 36-frame batch: determinism, frame independence, and a checksum of checksums."""
+def test_full_size_properties_config2_batch(orc):
+    """At BASELINE's full size with a 36-frame batch (large enough for the side-stream clear): determinism, frame
+    independence, a checksum of checksums, and three of the frames against the oracle bit for bit."""
     import srz
     ctx = srz.Context(0)
     ctx.texture_upload(0, scenes.spot_texture())
@@ -119,6 +120,11 @@ def test_full_size_properties_config2_batch():
     cov = torch.isfinite(a[:, 0]).sum(dim=(1, 2)).cpu().numpy()
     st = fs.stats()
     assert int(cov.sum()) == st["visible"] and (cov > 90_000).all() and (cov < 200_000).all()
+    got = a.cpu().numpy()
+    for i in (0, 17, 35):
+        rc, ref, _ = orc.draw(fr[i])
+        for p in range(4):
+            assert np.array_equal(bits(got[i, p]), bits(ref[p])), (i, p)
     ctx.close()
 
 
@@ -138,4 +144,58 @@ def test_device_resolve8_equals_display_resolve(orc, frames):
     for i in range(fs.n_frames):
         assert np.array_equal(got[i], orc.resolve8(tuple(host[i])))
     assert got[0, 0, :8, 0].tolist() == [0, 2, 2, 254, 255, 255, 0, 0]
+    ctx.close()
+
+
+def _random_frame(rng, w, h, n_tris, flags):
+    """Random soup: mostly small triangles, some large / off-screen / sliver ones, random normals, uvs beyond [0,1],
+    every shader, 0-3 lights — the shapes the tile masks, the per-frame work lists and the FastMath paths must survive."""
+    def tris(n):
+        t = np.zeros(n, abi.TRI_DTYPE)
+        c = rng.uniform([-0.1 * w, -0.1 * h], [1.1 * w, 1.1 * h], (n, 1, 2))
+        size = np.where(rng.random((n, 1, 1)) < 0.85, rng.uniform(1, 24, (n, 1, 1)), rng.uniform(24, 1.5 * max(w, h), (n, 1, 1)))
+        xy = c + rng.uniform(-1, 1, (n, 3, 2)) * size
+        snap = rng.random((n, 1, 1)) < 0.3          # vertices exactly on pixel corners: on-edge samples, exact zeros
+        xy = np.where(snap, np.round(xy), xy)
+        t["pos"][:, :, :2] = xy
+        t["pos"][:, :, 2] = rng.uniform(1, 90, (n, 1)) + rng.uniform(-0.5, 0.5, (n, 3))
+        t["nrm"] = rng.normal(0, 1, (n, 3, 3)) * rng.choice([1.0, 1e-3, 50.0], (n, 1, 1))
+        t["uv"] = rng.uniform(-0.2, 1.2, (n, 3, 2))
+        return t
+    shaders = [abi.SHADER_NORMAL, abi.SHADER_TEXTURE, abi.SHADER_PHONG, abi.SHADER_BUMP, abi.SHADER_DISPLACEMENT]
+    nb = int(rng.integers(1, 4))
+    batches = []
+    for b in range(nb):
+        sh = shaders[int(rng.integers(0, len(shaders)))]
+        batches.append((sh, 0 if sh in (abi.SHADER_TEXTURE, abi.SHADER_BUMP, abi.SHADER_DISPLACEMENT) else -1, tris(max(1, n_tris // nb))))
+    nl = int(rng.integers(0, 4))
+    lights = np.concatenate([rng.uniform([0, 0, -50], [w, h, 120], (nl, 1, 3)), rng.uniform(0, 400, (nl, 1, 3))], 1).astype(np.float32)
+    return abi.Frame(w, h, (0.0, 0.0, float(rng.uniform(0.5, 2.0))), lights, batches, flags, p=float(rng.choice([150.0, 8.0, 2.5])))
+
+
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SRZ_FUZZ_SEEDS", "8"))))
+def test_fuzz_random_frames_bit_identical_to_oracle(orc, seed):
+    """Seeded random batches (different content, batch structure, light count and exponent per frame) against the oracle."""
+    import srz
+    rng = np.random.default_rng(1000 + seed)
+    w, h = [(64, 64), (200, 120), (97, 131), (256, 96), (33, 290), (128, 128), (320, 200), (70, 70)][seed % 8]
+    flags = abi.FUSED_CLEAR | (abi.UNIFIED if seed % 3 == 2 else 0)
+    frames = [_random_frame(rng, w, h, int(rng.integers(1, 400)), flags) for _ in range(int(rng.integers(2, 12)))]
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    fs, out = render(ctx, frames, flags=0)           # flags come from the frames
+    got = out.cpu().numpy()
+    tot = {}
+    for i, f in enumerate(frames):
+        rc, ref, st = orc.draw(f)
+        assert rc == 0
+        for p in range(4):
+            same = bits(got[i, p]) == bits(ref[p])
+            assert same.all(), f"seed {seed} frame {i} plane {p}: {int((~same).sum())} words differ, first at {np.argwhere(~same)[0]}"
+        for k, v in st.items():
+            tot[k] = tot.get(k, 0) + v
+    assert fs.stats() == tot
     ctx.close()
