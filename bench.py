@@ -207,6 +207,13 @@ def main():
             "reference_published": {"fps": 58.6, "note": "README.md:619-629, i7-12800HX/MSVC, spot+crate 5-mesh scene, "
                                     "draw() incl. vertex stage — different workload/hardware, not reproducible here"},
         }
+        if world > 1:  # report the render and the exchange separately (rank 0's view)
+            step_ms = dt / args.steps * 1e3
+            res["multi_gpu"] = {"render_ms_per_step": kt["total_ms"], "exchange_ms_per_step": max(0.0, step_ms - kt["total_ms"]),
+                                "exchange": args.exchange,
+                                "bytes_received_per_rank_per_step": (world - 1) * (out.numel() * 4 if args.exchange == "planes" else bgr.numel()),
+                                "note": "exchange = RCCL all-gather of every rank's band shard + de-interleave to row-major; "
+                                        "xGMI-bound by construction (every rank receives (N-1)/N of every framebuffer)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_budget_s)
         print(json.dumps(res))
