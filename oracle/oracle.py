@@ -31,6 +31,7 @@ def lib():
         L.orc_draw.argtypes = [C.c_int, C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
         L.orc_draw_rows.argtypes = [C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.c_int, C.c_int]
         L.orc_draw_omp.argtypes = [C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.orc_draw_frames_omp.argtypes = [C.POINTER(C.POINTER(abi.SrzFrame)), C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_int)]
         L.orc_texture_set.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_vertex_stage.argtypes = [fp, C.c_void_p, C.c_uint32, fp, fp, fp, fp, C.c_float, C.c_float, C.c_void_p]
         L.orc_vertex_stage.restype = None
@@ -147,6 +148,14 @@ def draw_omp(frame, planes, band=16, threads=0):
     z, c0, c1, c2 = planes
     n = C.c_int(0)
     rc = lib().orc_draw_omp(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(band), C.byref(n), int(threads))
+    return rc, n.value
+
+
+def draw_frames_omp(frames, n_total, threads=0):
+    """clear + draw of n_total frames (round-robin over `frames`), whole frames per OpenMP thread → (rc, threads used)."""
+    arr = (C.POINTER(abi.SrzFrame) * len(frames))(*[C.pointer(f.c) for f in frames])
+    n = C.c_int(0)
+    rc = lib().orc_draw_frames_omp(arr, len(frames), int(n_total), int(threads), C.byref(n))
     return rc, n.value
 
 

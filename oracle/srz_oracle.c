@@ -707,6 +707,50 @@ int orc_draw_omp(const srz_frame *fr, float *z, float *c0, float *c1, float *c2,
   return rc;
 }
 
+/* CPU baseline, throughput form: whole frames dealt to OpenMP threads (each with its own four planes), `n_total` frames
+ * taken round-robin from `frames[0..n_unique)`; every frame is clear + draw through orc_draw (serial per frame).  This is
+ * the shape that uses every core of a large host: the row-band form above is limited by one frame's parallelism. */
+int orc_draw_frames_omp(const srz_frame *const *frames, int n_unique, long long n_total, int num_threads, int *threads_used) {
+  if (!frames || n_unique <= 0 || n_total < 0) return SRZ_E_INVALID;
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
+  int rc = SRZ_OK, nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp single
+    nthreads = omp_get_num_threads();
+#endif
+    size_t cap = 0;
+    float *pl = NULL;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long long i = 0; i < n_total; ++i) {
+      const srz_frame *fr = frames[i % n_unique];
+      const size_t px = (size_t)fr->width * (size_t)fr->height;
+      if (px > cap) {
+        free(pl);
+        pl = (float *)malloc(sizeof(float) * 4 * px);
+        cap = pl ? px : 0;
+      }
+      int r = pl ? orc_draw(SRZ_PRIMITIVE_TRIANGLES, fr, pl, pl + px, pl + 2 * px, pl + 3 * px, NULL) : SRZ_E_NOMEM;
+      if (r != SRZ_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        rc = r;
+      }
+    }
+    free(pl);
+  }
+  if (threads_used) *threads_used = nthreads;
+  return rc;
+}
+
 /* display() resolve (src/Render.cpp:61-62): merge planes 0,1,2 -> interleaved, convertTo(CV_8UC3) =
  * saturate_cast<uchar>(cvRound(v)) (round half to even) */
 void orc_resolve8(int W, int H, const float *c0, const float *c1, const float *c2, uint8_t *out) {
