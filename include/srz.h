@@ -216,8 +216,8 @@ int srz_frameset_stats(srz_ctx *ctx, srz_frameset *fs, srz_stats *stats);
  * 16*W*local_rows + 96*N_tri + 24*N_lights + B_tex per frame. n_shaded_tex = texture-shaded pixels. */
 uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *fs);
 /* Average device time (ms) per srz_frameset_render since the last call with reset!=0, measured with hipEvents on
- * the launch stream: ms4[0] = setup+binning kernels, ms4[1] = raster kernel (visibility + fused clear: writes the
- * framebuffer), ms4[2] = shade kernel, ms4[3] = whole pipeline. */
+ * the launch stream: ms4[0] = setup+binning kernels, ms4[1] = raster kernel (visibility), ms4[2] = shade kernel up to
+ * the join with the clear kernel that runs beside both on a second stream, ms4[3] = whole pipeline. */
 int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches);
 int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
 int srz_sync(srz_ctx *ctx);

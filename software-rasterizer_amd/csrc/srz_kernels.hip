@@ -4,25 +4,30 @@
 // Liupeter01/Software-Rasterizer) and the fragment shaders they call (src/Shader.cpp, include/shader/Shader.hpp).
 // Not a translation of the AVX2 code: the reference walks triangles serially and rows in parallel; here
 //
+//   k_vertex  one thread per face          (optional) the vertex stage, Scene::loadTriangleStream: meshes + matrices → srz_tri
 //   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox record
-//   k_bands   one WAVE per 32-row band     in-order scan of the BBox stream, ballot-compacted → per-band list of 48-byte
-//                                          RasterRec (positions + bbox + index), submission order preserved by
-//                                          construction: no atomics, no sort
-//   k_raster  one WAVE per 32x32 tile      VISIBILITY: tile z-buffer + owner-id planes in LDS; walks its band's list in
-//                                          order (next chunk prefetched), per triangle the 64 lanes cover 8x8 pixel blocks
-//                                          of bbox∩tile, run the coverage + z-test with the reference's per-column
-//                                          semantics and update LDS (a wave's LDS ops are ordered → "last writer in
-//                                          submission order wins" needs no lock).  Tiles nobody owns leave as the fused
-//                                          clear (16-byte non-temporal stores of +inf / 0); owned tiles write z + owner ids
-//                                          and enqueue themselves for shading.
+//   k_bands   one WORKGROUP per 32-row band ordered compaction of the BBox stream (count / scan / fill, hit masks in LDS) →
+//                                          per-band list of 48-byte RasterRec (positions + bbox + index), submission order
+//                                          preserved by construction: no atomics, no sort; + per-band mask of the tiles any
+//                                          listed bbox reaches
+//   k_clear   ~160 persistent workgroups   on a second stream beside k_raster / k_shade: the fused clear of every tile no
+//                                          bbox reaches (16-byte non-temporal stores of +inf / 0), throttled by its grid
+//   k_raster  one WAVE per touched tile    VISIBILITY: tile z-buffer + owner-id planes in LDS; walks its band's list in
+//                                          order (next chunk prefetched), per triangle the 64 lanes sweep pixel blocks of
+//                                          bbox∩tile, run the coverage + z-test with the reference's per-column semantics
+//                                          and update LDS (a wave's LDS ops are ordered → "last writer in submission order
+//                                          wins" needs no lock).  Touched tiles nobody owns leave as the fused clear; owned
+//                                          tiles write z + owner ids and append themselves to their frame's work list.
 //   k_shade   one WORKGROUP per owned tile VISIBILITY-FIRST SHADING: each pixel's final owner is shaded exactly once (the
 //                                          reference's shaders are pure functions of (triangle,pixel) and its write is an
-//                                          overwrite), all 1024 pixels of the tile in parallel, 16-byte stores of the 3
-//                                          colour planes.
+//                                          overwrite), pixels compacted by semantics class into dense 64-lane chunks,
+//                                          16-byte stores of the 3 colour planes.
+//   k_resolve8                             (optional) display(): planes → BGR8.
 //
 // Numerics: every float op is the oracle's op in the oracle's order (oracle/srz_oracle.c): contraction is OFF,
-// fused ops are explicit fmaf(), division and sqrt are the correctly rounded ones, pow is evaluated in binary64
-// and rounded once.  The z-buffer is therefore expected to be bit-identical to the oracle's.
+// fused ops are explicit fmaf(), division and sqrt are the correctly rounded ones (the compiler's IEEE expansions, or
+// short sequences proven / checked on the device to return the same bits), pow is evaluated in binary64 and rounded
+// once.  The framebuffer is therefore expected to be bit-identical to the oracle's.
 #include "srz_device.h"
 
 #include <algorithm>
