@@ -36,7 +36,7 @@ dbg_c = ctx.debug_counters()
 print("dbg cycles A,B,C,maxwave,shade_calls,blocks:", dbg_c[7:13])
 out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-ctx.set_kernel_timing(True)
+ctx.set_kernel_timing(not os.environ.get('PROBE_NO_TIMING'))
 for _ in range(3):
     fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | dbg, stream)
 torch.cuda.synchronize()
