@@ -44,6 +44,16 @@ def _worker(rank, world, port, height, width, q):
         full = parallel.all_gather_frames(shard, world, gathered)
         got = full.numpy()[:, :, :height]
         ok = all(np.array_equal(got[i].view(np.uint32), full_ref[i].view(np.uint32)) for i in range(len(frames)))
+
+        # the 8-bit exchange of bench.py --exchange bgr8: display()'s resolve per shard, same all-gather on uint8 rows
+        def to_bgr8(planes_f32):  # [frames, 4, rows, W] float → [frames, 1, rows, W*3] uint8 (round half to even, saturate)
+            c = torch.nan_to_num(planes_f32[:, 1:4], nan=0.0).round().clamp(0, 255).to(torch.uint8)
+            return c.permute(0, 2, 3, 1).reshape(c.shape[0], 1, c.shape[2], -1).contiguous()
+        shard8 = to_bgr8(shard)
+        gathered8 = torch.empty((world,) + tuple(shard8.shape), dtype=torch.uint8)
+        full8 = parallel.all_gather_frames(shard8, world, gathered8)
+        ref8 = to_bgr8(torch.from_numpy(np.stack(full_ref)))
+        ok = ok and torch.equal(full8[:, :, :height], ref8) and bool((ref8 > 0).any())
         q.put((rank, ok, tuple(full.shape)))
     finally:
         dist.destroy_process_group()
