@@ -249,7 +249,8 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in line (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
-  const bool side = any_fused && fs->max_tiles >= 8192;
+  const bool skip_clear = (flags_or & 0x2000u) != 0; // dev probe only (SRZ_DEBUG_FLAGS): leaves untouched tiles unwritten
+  const bool side = any_fused && fs->max_tiles >= 8192 && !skip_clear;
   unsigned ev = 0;
   if (side) {
     if (!ctx->stream2) {
@@ -264,7 +265,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork[ev], 0));
     launch_clear(a, fs->max_tiles, true, ctx->stream2);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], ctx->stream2));
-  } else if (any_fused) {
+  } else if (any_fused && !skip_clear) {
     launch_clear(a, fs->max_tiles, false, s);
   }
   launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);

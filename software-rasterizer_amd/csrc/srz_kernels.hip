@@ -993,45 +993,42 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
 // the back), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
 // colours go to LDS planes and leave as coalesced 16-byte stores.
 // ================================================================================================================
-// The clear of one tile nobody owns (z = +inf, colour 0; src/Render.cpp:46-55 restricted to the tile): pure 16-byte
-// streaming stores, issued by k_shade between two shaded tiles so that they drain under the shading arithmetic.
-__device__ __forceinline__ void clear_tile(const RenderArgs &a, uint32_t e, int tid) {
-  const uint32_t tx = e % a.tiles_x, rest = e / a.tiles_x;
-  const uint32_t lb = rest % a.n_local_bands, f = rest / a.n_local_bands;
-  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
-  const int W = fd->width, H = fd->height;
-  const int band = (int)lb * a.shard_world + a.shard_rank;
-  const int tx0 = (int)tx * TILE, ty0 = band * BAND;
-  const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
-  const size_t plane = (size_t)a.local_rows * (size_t)W;
-  const int ly = tid >> 3, lx4 = (tid & 7) * 4;
-  const int y = ty0 + ly, x4 = tx0 + lx4;
-  if (y > ty1 || x4 > tx1) return;
-  float *gz = a.out + (size_t)f * a.frame_stride + ((size_t)lb * BAND + ly) * (size_t)W + x4;
-  const float inf = __builtin_inff();
-  if (((W & 3) == 0) && x4 + 3 <= tx1) {
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    store_nt(gz, make_float4(inf, inf, inf, inf));
-    store_nt(gz + plane, zero4);
-    store_nt(gz + 2 * plane, zero4);
-    store_nt(gz + 3 * plane, zero4);
-  } else {
-    for (int k = 0; k < 4; ++k)
-      if (x4 + k <= tx1) gz[k] = inf, gz[plane + k] = 0.f, gz[2 * plane + k] = 0.f, gz[3 * plane + k] = 0.f;
-  }
-}
-
 // k_clear — the fused clear of every tile NO bbox reaches (k_bands' tile masks), i.e. most of the framebuffer.  It runs
 // on a second stream NEXT TO k_raster, which skips those tiles: no LDS and < 32 VGPRs, so its waves fit beside the
 // rasteriser's on every CU and the bulk of the frame's HBM writes drains under the visibility arithmetic.
+// One work item = one band of one frame, written ROW-MAJOR: a wave-instruction covers 1 KiB of one framebuffer row
+// (256 consecutive pixels), so runs of untouched tiles become long contiguous DRAM bursts instead of 128-byte tile rows
+// 4 KiB apart — the same bytes occupy the memory system for less time, which is what the kernels beside it pay for.
 __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
-  const uint32_t tpf = a.n_local_bands * a.tiles_x, total = a.n_frames * tpf;
-  for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
-    const uint32_t tx = e % a.tiles_x, row = e / a.tiles_x; // row = frame * n_local_bands + lb
-    const uint32_t word = as_const(a.tile_mask)[(size_t)row * a.mask_words + (tx >> 5)];
-    if ((word >> (tx & 31u)) & 1u) continue;
-    const uint32_t flags = as_const(a.frames)[row / a.n_local_bands].flags | a.flags_or;
-    if (flags & SRZ_FUSED_CLEAR) clear_tile(a, e, threadIdx.x);
+  const uint32_t n_rows = a.n_frames * a.n_local_bands;
+  const float inf = __builtin_inff();
+  const float4 inf4 = make_float4(inf, inf, inf, inf), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint32_t br = blockIdx.x; br < n_rows; br += gridDim.x) { // br = frame * n_local_bands + lb
+    const uint32_t f = br / a.n_local_bands, lb = br % a.n_local_bands;
+    const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
+    if (!((fd->flags | a.flags_or) & SRZ_FUSED_CLEAR)) continue;
+    const int W = fd->width, H = fd->height;
+    const int band = (int)lb * a.shard_world + a.shard_rank;
+    const int rows = min(BAND, H - band * BAND);
+    const size_t plane = (size_t)a.local_rows * (size_t)W;
+    float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W;
+    const SRZ_CAS uint32_t *mask = as_const(a.tile_mask) + (size_t)br * a.mask_words;
+    for (int x4 = (int)threadIdx.x * 4; x4 < W; x4 += 256 * 4) {
+      const uint32_t tx = (uint32_t)x4 / TILE;
+      if ((mask[tx >> 5] >> (tx & 31u)) & 1u) continue; // some bbox reaches this tile: k_raster's
+      if (((W & 3) == 0)) {
+        for (int ly = 0; ly < rows; ++ly) {
+          float *g = base + (size_t)ly * W + x4;
+          store_nt(g, inf4), store_nt(g + plane, zero4), store_nt(g + 2 * plane, zero4), store_nt(g + 3 * plane, zero4);
+        }
+      } else { // odd widths: scalar stores, the quad may end at the frame's edge or straddle nothing else (TILE % 4 == 0)
+        for (int ly = 0; ly < rows; ++ly)
+          for (int k = 0; k < 4 && x4 + k < W; ++k) {
+            float *g = base + (size_t)ly * W + x4 + k;
+            g[0] = inf, g[plane] = 0.f, g[2 * plane] = 0.f, g[3 * plane] = 0.f;
+          }
+      }
+    }
   }
 }
 
@@ -1375,12 +1372,14 @@ void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_coun
 
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s) {
   if (max_tiles == 0) return;
-  // Beside k_raster/k_shade the clear is THROTTLED by its grid size: ~160 workgroups write at roughly half the HBM
-  // rate, so the stores spread over the whole pipeline instead of starving the rasteriser's loads (measured on
-  // MI355X, 256 frames of 1024^2: 64 WGs → clear outlives k_shade, 1024 → k_raster +80 %; flat optimum 128..192).
+  // Beside k_raster/k_shade the clear is THROTTLED by its grid size, so that the stores spread over the whole pipeline
+  // instead of starving the rasteriser's loads and the shader's register file (measured on MI355X, 256 frames of 1024^2:
+  // 32 WGs → the clear outlives k_shade, 160 → k_raster +50 %; flat optimum around 64).
   static const uint32_t env = getenv("SRZ_CLEAR_WGS") ? (uint32_t)atoi(getenv("SRZ_CLEAR_WGS")) : 0u;
-  const uint32_t cap = !beside_raster ? 2048u : (env ? env : 160u);
-  hipLaunchKernelGGL(k_clear, dim3(max_tiles < cap ? max_tiles : cap), dim3(256), 0, s, a);
+  const uint32_t n_rows = a.n_frames * a.n_local_bands;
+  const uint32_t cap = !beside_raster ? 2048u : (env ? env : 64u);
+  (void)max_tiles;
+  hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(256), 0, s, a);
 }
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s) {

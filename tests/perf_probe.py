@@ -18,12 +18,15 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dbg = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
+BASE_FLAGS = int(os.environ.get('PROBE_FLAGS', str(abi.FUSED_CLEAR)), 0)
 builder = {2: scenes.config2, 3: scenes.config3, 4: scenes.config4, 5: scenes.config5}[cfg]
 t0 = time.time()
 import os
 kw = {}
 if os.environ.get('PROBE_SHADER') is not None and cfg == 2:
     kw['shader'] = int(os.environ['PROBE_SHADER'])
+if os.environ.get('PROBE_FRAME_FLAGS') is not None:
+    kw['flags'] = int(os.environ['PROBE_FRAME_FLAGS'], 0)
 uniq = [builder(i, **kw) for i in range(min(F, 36))]
 frames = [uniq[i % len(uniq)] for i in range(F)]
 print(f"built {len(uniq)} frames in {time.time()-t0:.1f}s; tris/frame={frames[0].n_tris}")
@@ -38,12 +41,12 @@ out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 ctx.set_kernel_timing(not os.environ.get('PROBE_NO_TIMING'))
 for _ in range(3):
-    fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | dbg, stream)
+    fs.render(out.data_ptr(), fs.out_bytes, BASE_FLAGS | dbg, stream)
 torch.cuda.synchronize()
 ctx.kernel_time_ms(True)
 t0 = time.time()
 for _ in range(iters):
-    fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | dbg, stream)
+    fs.render(out.data_ptr(), fs.out_bytes, BASE_FLAGS | dbg, stream)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / iters
 kt = ctx.kernel_time_ms(True)
