@@ -168,6 +168,12 @@ int srz_mesh_upload(srz_ctx *ctx, int mesh_id, const srz_vertex *verts, uint32_t
 int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, float *c0, float *c1,
              float *c2, srz_stats *stats);
 
+/* Batch form of srz_draw (host buffers): n frames of one size in one launch set.  planes[f] points to 4*W*H floats of
+ * frame f laid out [z | c0 | c1 | c2], in/out like srz_draw's four pointers.  stats (optional) = sums over the batch.
+ * One upload + one download over PCIe per call; for data that stays on the device use the frameset calls below. */
+int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_frames, float *const *planes,
+                   srz_stats *stats);
+
 /* ---- throughput mode: frames resident in HBM ------------------------------------------
  * A frameset copies n frames (same width/height) to the device once.  srz_frameset_render
  * rasterises + shades all of them into ONE device buffer laid out

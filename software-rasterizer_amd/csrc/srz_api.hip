@@ -965,4 +965,39 @@ int srz_draw_scene(srz_ctx *ctx, int primitive, const srz_scene_frame *frame, fl
   return draw_impl(ctx, primitive, nullptr, frame, z, c0, c1, c2, stats);
 }
 
+int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_frames, float *const *planes, srz_stats *stats) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (primitive != SRZ_PRIMITIVE_LINES && primitive != SRZ_PRIMITIVE_TRIANGLES)
+    return fail(ctx, SRZ_E_PRIMITIVE, "Primitive Type is not supported!");
+  if (!frames || n_frames <= 0 || !planes) return fail(ctx, SRZ_E_INVALID, "srz_draw_batch: null argument");
+  for (int f = 0; f < n_frames; ++f)
+    if (!planes[f]) return fail(ctx, SRZ_E_INVALID, "srz_draw_batch: null plane pointer");
+  if (ctx->shard_world != 1) return fail(ctx, SRZ_E_INVALID, "srz_draw_batch: whole-frame draw needs an unsharded ctx");
+  srz_frameset *fs = nullptr;
+  int rc = srz_frameset_create(ctx, frames, n_frames, &fs);
+  if (rc) return rc;
+  const size_t fb = 4ull * (size_t)fs->width * (size_t)fs->height * sizeof(float); // one frame: z,c0,c1,c2 planes
+  float *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_out, fb * (size_t)n_frames);
+  if (e != hipSuccess) {
+    srz_frameset_destroy(ctx, fs);
+    return fail(ctx, SRZ_E_NOMEM, "srz_draw_batch: hipMalloc failed");
+  }
+  hipStream_t s = ctx->stream;
+  for (int f = 0; f < n_frames && e == hipSuccess; ++f) // accumulate-mode frames start from the caller's planes
+    if (!(frames[f].flags & SRZ_FUSED_CLEAR))
+      e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_out) + fb * f, planes[f], fb, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = render_impl(ctx, fs, d_out, 0, s, stats != nullptr);
+    if (rc == SRZ_OK && stats) rc = read_stats(ctx, s, stats);
+  }
+  for (int f = 0; f < n_frames && e == hipSuccess && rc == SRZ_OK; ++f)
+    e = hipMemcpyAsync(planes[f], reinterpret_cast<uint8_t *>(d_out) + fb * f, fb, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_out);
+  srz_frameset_destroy(ctx, fs);
+  if (e != hipSuccess) return fail(ctx, SRZ_E_NODEVICE, std::string("srz_draw_batch: ") + hipGetErrorString(e));
+  return rc;
+}
+
 } // extern "C"

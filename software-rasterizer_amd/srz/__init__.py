@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath", "srz_verify_fastdiv"]
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch"]
 
 
 class SrzError(RuntimeError):
@@ -43,6 +43,7 @@ def lib():
         L.srz_set_shard.argtypes = [vp, C.c_int, C.c_int]
         L.srz_texture_upload.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
         L.srz_draw.argtypes = [vp, C.c_int, C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
+        L.srz_draw_batch.argtypes = [vp, C.c_int, C.POINTER(abi.SrzFrame), C.c_int, C.POINTER(fp), C.POINTER(abi.SrzStats)]
         L.srz_frameset_create.argtypes = [vp, C.POINTER(abi.SrzFrame), C.c_int, C.POINTER(vp)]
         L.srz_sceneset_create.argtypes = [vp, C.POINTER(abi.SrzSceneFrame), C.c_int, C.POINTER(vp)]
         L.srz_mesh_upload.argtypes = [vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32]
@@ -164,6 +165,18 @@ class Context:
         fn = lib().srz_draw_scene if isinstance(frame, abi.SceneFrame) else lib().srz_draw
         self._check(fn(self.h, primitive, C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2),
                        C.byref(st) if want_stats else None))
+        return planes, (st.as_dict() if want_stats else None)
+
+    def draw_batch(self, frames, planes=None, primitive=abi.PRIMITIVE_TRIANGLES, want_stats=False):
+        """srz_draw_batch: planes = float32 array [n, 4, H, W] (z, c0, c1, c2 per frame), modified in place."""
+        n, h, w = len(frames), frames[0].height, frames[0].width
+        if planes is None:
+            planes = np.zeros((n, 4, h, w), np.float32)
+            planes[:, 0] = np.inf
+        assert planes.dtype == np.float32 and planes.shape == (n, 4, h, w) and planes.flags.c_contiguous
+        ptrs = (lib().srz_draw_batch.argtypes[4]._type_ * n)(*[_fp(planes[i]) for i in range(n)])
+        st = abi.SrzStats()
+        self._check(lib().srz_draw_batch(self.h, primitive, abi.frames_array(frames), n, ptrs, C.byref(st) if want_stats else None))
         return planes, (st.as_dict() if want_stats else None)
 
     def frameset(self, frames):

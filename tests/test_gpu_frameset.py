@@ -199,3 +199,32 @@ def test_fuzz_random_frames_bit_identical_to_oracle(orc, seed):
             tot[k] = tot.get(k, 0) + v
     assert fs.stats() == tot
     ctx.close()
+
+
+def test_draw_batch_host_buffers_equal_per_frame_draw(orc):
+    """srz_draw_batch (host planes in/out, one launch set) = srz_draw frame by frame = the oracle; one frame of the batch
+    accumulates into caller-provided planes (no clear), the others are fused-clear."""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    fr = [scenes.config2(i, size=256) for i in (0, 5, 9)]
+    fr[1] = scenes.config2(5, size=256, flags=0)                      # accumulate: starts from the given planes
+    planes = np.zeros((3, 4, 256, 256), np.float32)
+    planes[:, 0] = np.inf
+    planes[1, 0, 100:140] = 1.0                                        # a near "wall" across 40 rows: occludes the spot there
+    planes[1, 1:4, 100:140] = 77.0
+    init1 = tuple(planes[1, p].copy() for p in range(4))
+    got, st = ctx.draw_batch(fr, planes, want_stats=True)
+    tot = {}
+    for i, f in enumerate(fr):
+        rc, ref, s1 = orc.draw(f, init1 if i == 1 else None)
+        assert rc == 0
+        for p in range(4):
+            assert np.array_equal(bits(got[i, p]), bits(ref[p])), (i, p)
+        for k, v in s1.items():
+            tot[k] = tot.get(k, 0) + v
+    assert st == tot
+    assert (got[1, 1, 100:140] == 77.0).all()
+    with pytest.raises(srz.SrzError):
+        ctx.draw_batch(fr, planes, primitive=7)
+    ctx.close()
