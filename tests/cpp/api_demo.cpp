@@ -81,6 +81,13 @@ int main(int argc, char **argv) {
       scene->setProjectionMatrix(45.0f, 0.1f, 100.0f);
       render->display(SoftRasterizer::Primitive::TRIANGLES);
     }
+    if (argc > 2) { // dump the last frame (degree = 130) as raw float planes z,c0,c1,c2 for the oracle comparison
+      std::FILE *fp = std::fopen(argv[2], "wb");
+      if (!fp) return 1;
+      std::fwrite(render->zBuffer().data(), 4, 256 * 256, fp);
+      for (int c = 0; c < 3; ++c) std::fwrite(render->channel(c).data(), 4, 256 * 256, fp);
+      std::fclose(fp);
+    }
     bool threw = false;
     try {
       render->draw(static_cast<SoftRasterizer::Primitive>(7));
