@@ -72,7 +72,7 @@ struct srz_frameset {
   srz_light *d_lights = nullptr;
   RasterRec *d_band_recs = nullptr;
   uint32_t *d_band_count = nullptr;
-  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_tile_mask = nullptr;
+  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_tile_mask = nullptr, *d_chunk_rows = nullptr;
   uint32_t mask_words = 0;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
@@ -140,6 +140,7 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_worklist);
   (void)hipFree(fs->d_work_count);
   (void)hipFree(fs->d_tile_mask);
+  (void)hipFree(fs->d_chunk_rows);
   (void)hipFree(fs->d_sdesc);
   (void)hipFree(fs->d_draws);
   (void)hipFree(fs->d_band_count);
@@ -150,6 +151,7 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.frames = fs->d_frames;
   a.tris = fs->d_tris;
   a.bbox = fs->d_bbox;
+  a.chunk_rows = fs->d_chunk_rows;
   a.tri_batch = fs->d_tri_batch;
   a.batches = fs->d_batches;
   a.lights = fs->d_lights;
@@ -472,6 +474,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_frames, sizeof(FrameDesc) * n_frames));
   FS_TRY(dev_alloc((void **)&fs->d_tris, sizeof(srz_tri) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_bbox, sizeof(BBox) * tri_off));
+  FS_TRY(dev_alloc((void **)&fs->d_chunk_rows, sizeof(uint32_t) * (tri_off / 64 + (size_t)n_frames + 1)));
   FS_TRY(dev_alloc((void **)&fs->d_tri_batch, sizeof(uint16_t) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));

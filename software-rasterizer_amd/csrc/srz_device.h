@@ -88,6 +88,7 @@ struct RenderArgs {
   const FrameDesc *frames;
   const srz_tri *tris;
   const BBox *bbox;
+  uint32_t *chunk_rows;          // per 64-triangle chunk: min sy | max ey << 16 of its kept triangles (k_setup → k_bands)
   const uint16_t *tri_batch;
   const BatchDesc *batches;
   const srz_light *lights;

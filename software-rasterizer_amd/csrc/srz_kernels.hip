@@ -284,12 +284,13 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
   const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
   const float ex = fd->eye[0], ey = fd->eye[1], ez = fd->eye[2];
   unsigned long long n_culled = 0, tests = 0;
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n_tris; t += gridDim.x * 256) {
-    const SRZ_CAS float *p = as_const(&a.tris[tri_off + t].pos[0][0]);
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; (t & ~63u) < n_tris; t += gridDim.x * 256) { // whole waves
+    const bool live = t < n_tris;
+    const SRZ_CAS float *p = as_const(&a.tris[tri_off + (live ? t : 0u)].pos[0][0]);
     float A0 = p[0], A1 = p[1], A2 = p[2], B0 = p[3], B1 = p[4], B2 = p[5], C0 = p[6], C1 = p[7], C2 = p[8];
     BBox bb;
     bb.sx = 1, bb.sy = 1, bb.ex = 0, bb.ey = 0;
-    bool finite = __builtin_isfinite(A0) && __builtin_isfinite(A1) && __builtin_isfinite(A2) && __builtin_isfinite(B0) &&
+    bool finite = live && __builtin_isfinite(A0) && __builtin_isfinite(A1) && __builtin_isfinite(A2) && __builtin_isfinite(B0) &&
                   __builtin_isfinite(B1) && __builtin_isfinite(B2) && __builtin_isfinite(C0) && __builtin_isfinite(C1) &&
                   __builtin_isfinite(C2);
     bool keep = false;
@@ -316,10 +317,15 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
       bb.sy = (int16_t)(int)std_clamp(mny, 0.0f, (float)(H - 1));
       bb.ey = (int16_t)(int)std_clamp(mxy, 0.0f, (float)(H - 1));
       if (STATS) tests += (unsigned long long)(bb.ex - bb.sx + 1) * (unsigned long long)(bb.ey - bb.sy + 1);
-    } else if (STATS) {
+    } else if (STATS && live) {
       n_culled++;
     }
-    bbox_out[tri_off + t] = bb;
+    if (live) bbox_out[tri_off + t] = bb;
+    // rows spanned by the kept triangles of this 64-triangle chunk (= this wave's 64 consecutive t): lets k_bands skip
+    // the chunks that cannot reach a band without reading their 64 bboxes
+    int lo = keep ? (int)bb.sy : 0x7fff, hi = keep ? (int)bb.ey : -1;
+    for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));
+    if ((threadIdx.x & 63) == 0) a.chunk_rows[tri_off / 64u + blockIdx.y + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
   }
   if (STATS) {
     if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
@@ -368,6 +374,7 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
   RasterRec *out = band_recs + fd->list_off + (uint64_t)lb * n_tris;
   const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
   const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
+  const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->tri_off / 64u + blockIdx.y;
   uint32_t *qi = s_q + 256 * wave, *qp = qi + 128;
   const unsigned long long lt = (1ull << lane) - 1ull;
   auto hit_mask = [&](uint32_t chunk) -> unsigned long long {
@@ -401,10 +408,23 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
   uint32_t base = 0; // records written by earlier super-blocks
   for (uint32_t sb = 0; sb < n_chunks; sb += chunks_cap) {
     const uint32_t nc = min(chunks_cap, n_chunks - sb);
-    // ---- pass 1: per-chunk hit counts ------------------------------------------------------------------------------
-    for (uint32_t c = (uint32_t)wave; c < nc; c += BANDS_WAVES) {
-      const unsigned long long m = hit_mask(sb + c);
-      if (lane == 0) s_mask[c] = m, s_off[c] = (uint32_t)__popcll(m);
+    // ---- pass 1: per-chunk hit counts.  A wave first tests the row ranges of 64 chunks at once (one word per chunk,
+    //      written by k_setup) and ballots the bboxes only of the chunks that can reach this band -----------------------
+    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < nc; c0 += 64u * (uint32_t)BANDS_WAVES) {
+      bool cand = false;
+      const uint32_t c = c0 + (uint32_t)lane;
+      if (c < nc) {
+        const uint32_t r = chunk_rows[sb + c];
+        cand = (int)(int16_t)(r & 0xffffu) <= y1 && (int)(int16_t)(r >> 16) >= y0;
+        if (!cand) s_mask[c] = 0ull, s_off[c] = 0u;
+      }
+      unsigned long long mc = __ballot(cand);
+      while (mc) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(mc);
+        mc &= mc - 1;
+        const unsigned long long m = hit_mask(sb + c0 + j);
+        if (lane == 0) s_mask[c0 + j] = m, s_off[c0 + j] = (uint32_t)__popcll(m);
+      }
     }
     __syncthreads();
     // ---- scan (wave 0): exclusive prefix of the counts -------------------------------------------------------------
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
     // ---- pass 2: ordered fill ----------------------------------------------------------------------------------------
     uint32_t nq = 0;
     for (uint32_t c = (uint32_t)wave; c < nc; c += BANDS_WAVES) {
-      const unsigned long long m = s_mask[c]; // (this wave wrote it in pass 1)
+      const unsigned long long m = s_mask[c];
       if (m == 0ull) continue;
       if ((m >> lane) & 1ull) {
         const uint32_t k = nq + (uint32_t)__popcll(m & lt);
