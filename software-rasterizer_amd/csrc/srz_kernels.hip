@@ -377,16 +377,6 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
   const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->tri_off / 64u + blockIdx.y;
   uint32_t *qi = s_q + 256 * wave, *qp = qi + 128;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  auto hit_mask = [&](uint32_t chunk) -> unsigned long long {
-    const uint32_t t = chunk * 64 + lane;
-    bool hit = false;
-    if (t < n_tris) {
-      const u32x2 r = bbox[t];
-      const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
-      hit = sx <= ex && sy <= y1 && ey >= y0;
-    }
-    return __ballot(hit);
-  };
   auto flush = [&](uint32_t n) { // n <= 64 queued (index, slot) pairs → records
     if ((uint32_t)lane < n) {
       const uint32_t t = qi[lane], pos = qp[lane];
@@ -419,11 +409,27 @@ __global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, Ra
         if (!cand) s_mask[c] = 0ull, s_off[c] = 0u;
       }
       unsigned long long mc = __ballot(cand);
-      while (mc) {
-        const uint32_t j = (uint32_t)__builtin_ctzll(mc);
-        mc &= mc - 1;
-        const unsigned long long m = hit_mask(sb + c0 + j);
-        if (lane == 0) s_mask[c0 + j] = m, s_off[c0 + j] = (uint32_t)__popcll(m);
+      while (mc) { // four candidates per step: their bbox loads are issued back to back (unconditionally, from a clamped
+                   // index) so that one round trip serves four chunks instead of one
+        uint32_t jj[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ok[u] = mc != 0ull;
+          jj[u] = ok[u] ? (uint32_t)__builtin_ctzll(mc) : 0u;
+          mc &= mc - 1ull; // (0 stays 0)
+        }
+        u32x2 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = bbox[min((sb + c0 + jj[u]) * 64u + (uint32_t)lane, n_tris - 1u)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) break; // wave-uniform
+          const bool live = (sb + c0 + jj[u]) * 64u + (uint32_t)lane < n_tris;
+          const int sx = (int16_t)(r[u].x & 0xffff), sy = (int16_t)(r[u].x >> 16), ex = (int16_t)(r[u].y & 0xffff), ey = (int16_t)(r[u].y >> 16);
+          const unsigned long long m = __ballot(live && sx <= ex && sy <= y1 && ey >= y0);
+          if (lane == 0) s_mask[c0 + jj[u]] = m, s_off[c0 + jj[u]] = (uint32_t)__popcll(m);
+        }
       }
     }
     __syncthreads();
