@@ -479,7 +479,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));
   fs->max_tiles = (uint32_t)n_frames * fs->n_local_bands * fs->tiles_x;
-  FS_TRY(dev_alloc((void **)&fs->d_band_recs, sizeof(RasterRec) * list_off));
+  FS_TRY(dev_alloc((void **)&fs->d_band_recs, sizeof(RasterRec) * (list_off + 64))); // + one speculative chunk (k_raster)
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
   FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
   FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * n_frames));

@@ -802,18 +802,18 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   const unsigned long long tB = STATS ? __builtin_readcyclecounter() : 0;
   unsigned long long n_blocks = 0;
   // ---- phase B: walk the band's triangle list in submission order ---------------------------------------------
-  const uint32_t cnt = (flags & 0x100u) ? 0u : a.band_count[fd->count_off + lb];
+  // (the list length does not depend on the frame descriptor — count_off = frame * n_local_bands by construction — so
+  // its load is in flight together with the descriptor's, and the first chunk of records is fetched SPECULATIVELY for all
+  // 64 lanes before the length is known: two dependent round trips per tile instead of three.  The list region is padded,
+  // lanes beyond the length are masked.)
+  const uint32_t cnt = (flags & 0x100u) ? 0u : as_const(a.band_count)[frame * a.n_local_bands + lb];
   const SRZ_CAS f32x4 *recs =
       reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.band_recs) + fd->list_off + (uint64_t)lb * n_tris);
   unsigned long long n_frag = 0, n_shaded = 0;
 
   // software pipeline: the next chunk's records are in flight while the current chunk is rasterised
-  f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0, n2 = n0;
-  bool nv = false;
-  if ((uint32_t)lane < cnt) {
-    n0 = recs[3 * lane], n1 = recs[3 * lane + 1], n2 = recs[3 * lane + 2];
-    nv = true;
-  }
+  f32x4 n0 = recs[3 * lane], n1 = recs[3 * lane + 1], n2 = recs[3 * lane + 2];
+  bool nv = (uint32_t)lane < cnt;
   for (uint32_t base = 0; base < cnt; base += 64) {
     const f32x4 r0 = n0, r1 = n1, r2 = n2;
     const bool valid = nv;
