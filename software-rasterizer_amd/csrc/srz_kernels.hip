@@ -672,7 +672,7 @@ template <class M> __device__ __forceinline__ void unpack_tri(M &m, const TriFet
 }
 // Shade pixel (x,y) of depth z, owner `f`, 8-wide ("V") semantics (src/Rasterizer.cpp:380-389)
 template <class M>
-__device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
+__device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
   unpack_tri(m, f, a);
@@ -685,11 +685,11 @@ __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const Shade
   v_normalized(m, nx, ny, nz);
   float u = fmaf_(alpha, a.u0, fmaf_(beta, a.u1, gamma * a.u2));
   float v = fmaf_(alpha, a.v0, fmaf_(beta, a.v1, gamma * a.v2));
-  v_shade(m, K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+  v_shade(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2); // zz: the depth k_raster stored (same operations)
 }
 // scalar-tail ("S") semantics (src/Rasterizer.cpp:470-492)
 template <class M>
-__device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y, float z,
+__device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
   unpack_tri(m, f, a);
@@ -702,7 +702,7 @@ __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const Shade
   normalize3(m, nx, ny, nz);
   float u = alpha * a.u0 + beta * a.u1 + gamma * a.u2;
   float v = alpha * a.v0 + beta * a.v1 + gamma * a.v2;
-  s_shade(m, K, sd, fx, fy, z, nx, ny, nz, u, v, r0, r1, r2);
+  s_shade(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2);
 }
 
 #ifdef SRZ_ISA_PROBE
@@ -722,11 +722,11 @@ __global__ void probe_v(RenderArgs a, float *o) {
   float r0, r1, r2;
 #ifdef SRZ_PROBE_S
   FastMath fm;
-  shade_pixel_s(fm, K, sd, tf, threadIdx.x, blockIdx.x, o[threadIdx.x], r0, r1, r2);
+  shade_pixel_s(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #else
   FastMath fm;
-  shade_pixel_v(fm, K, sd, tf, threadIdx.x, blockIdx.x, o[threadIdx.x], r0, r1, r2);
+  shade_pixel_v(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #endif
   o[threadIdx.x] = r0 + r1 + r2;
@@ -963,8 +963,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
         const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
         uint32_t *gv = vis0 + (size_t)ly * W + x4;
         if (full) {
-          *reinterpret_cast<float4 *>(gz) = z4; // re-read by k_shade: keep it cacheable
-          *reinterpret_cast<uint4 *>(gv) = id4;
+          store_nt(gz, z4);                      // final: k_shade recomputes the depth it needs from the owner triangle
+          *reinterpret_cast<uint4 *>(gv) = id4; // re-read by k_shade: keep it cacheable
         } else {
 #define SRZ_ST(K_, M)                                                                                                  \
   if (x4 + K_ <= tx1) gz[K_] = z4.M, gv[K_] = id4.M;
@@ -1065,7 +1065,6 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 template <bool STATS>
 __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
-  __shared__ __attribute__((aligned(16))) float s_zv[TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];
   __shared__ uint32_t s_wcnt[4][2]; // per wave: V-class and S-class pixels among its 256
@@ -1112,17 +1111,18 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
     float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
     const uint32_t *vis0 = a.vis + ((size_t)f * a.local_rows + row0) * (size_t)W;
 
-    // ---- 1. load this thread's 4 pixels (z, owner id, old colour unless fused) into LDS, classify, compact ------
+    // ---- 1. load this thread's 4 pixels (owner id, old colour unless fused) into LDS, classify, compact ----------
+    //         (the z plane is not read: the shader's depth is recomputed from the owner triangle with k_raster's own
+    //         operations, which is cheaper than 4 bytes per pixel of HBM read)
     const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int y = ty0 + ly, x4 = tx0 + lx4;
     const bool in_tile = y <= ty1 && x4 <= tx1;
     const bool full = in_tile && ((W & 3) == 0) && x4 + 3 <= tx1;
     float *gz = out0 + (size_t)ly * W + x4;
     const uint32_t *gv = vis0 + (size_t)ly * W + x4;
-    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), C0 = z4, C1 = z4, C2 = z4;
+    float4 C0 = make_float4(0.f, 0.f, 0.f, 0.f), C1 = C0, C2 = C0;
     uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
     if (full) {
-      z4 = *reinterpret_cast<const float4 *>(gz);
       id4 = *reinterpret_cast<const uint4 *>(gv);
       if (!fused) { // keep the colour of pixels this call does not own
         C0 = *reinterpret_cast<const float4 *>(gz + plane);
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
     } else if (in_tile) {
 #define SRZ_LD(K_, M)                                                                                                  \
   if (x4 + K_ <= tx1) {                                                                                                \
-    z4.M = gz[K_], id4.M = gv[K_];                                                                                     \
+    id4.M = gv[K_];                                                                                                    \
     if (!fused) C0.M = gz[plane + K_], C1.M = gz[2 * plane + K_], C2.M = gz[3 * plane + K_];                           \
   }
       SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
@@ -1140,7 +1140,6 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
     }
     if (flags & 0x200u) id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
     const int p0 = ly * TILE + lx4;
-    *reinterpret_cast<float4 *>(&s_zv[p0]) = z4;
     *reinterpret_cast<uint4 *>(&s_ids[p0]) = id4;
     *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
@@ -1207,9 +1206,9 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
           if (flags & 0x1000u)
             r0 = tf.q0.x + tf.q5.w + (float)tf.batch, r1 = tf.q3.y + tf.q2.x + tf.q1.x, r2 = tf.q4.z + (float)sd.tw;
           else if (isV)
-            shade_pixel_v(m, K, sd, tf, px, py, s_zv[p], r0, r1, r2);
+            shade_pixel_v(m, K, sd, tf, px, py, r0, r1, r2);
           else
-            shade_pixel_s(m, K, sd, tf, px, py, s_zv[p], r0, r1, r2);
+            shade_pixel_s(m, K, sd, tf, px, py, r0, r1, r2);
           if constexpr (std::is_same<M, FastMath>::value) bad |= m.bad;
         }
         s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
