@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRZ_ABI_VERSION 1
+#define SRZ_ABI_VERSION 2
 
 /* error codes */
 #define SRZ_OK 0
@@ -55,6 +55,8 @@ extern "C" {
 #define SRZ_EXACT_SPLIT 0u /* default: reproduce the reference's AVX-columns / scalar-tail split per (triangle,pixel) */
 #define SRZ_UNIFIED 1u     /* every pixel uses the 8-wide ("AVX") semantics; NOT reference-exact, for A/B only */
 #define SRZ_FUSED_CLEAR 2u /* treat z/colour as just cleared (clear(Color|Depth), src/Render.cpp:46-55): write-only framebuffer */
+#define SRZ_ORDERED_RASTER 4u /* rasterise every tile with the reference's ordered triangle walk (src/Rasterizer.cpp:199-236)
+                               * instead of the order-independent depth keys; same result bit for bit, slower; for A/B only */
 
 /* Post-MVP triangle = payload of SoftRasterizer::Triangle that draw() consumes
  * (m_vertex/m_normal/m_texCoords, include/object/Triangle.hpp:88-93).  Screen-space x,y in pixels,
@@ -93,7 +95,7 @@ typedef struct srz_frame {
   uint32_t n_batches;
   const srz_light *lights;
   const srz_batch *batches;
-  uint32_t flags; /* SRZ_EXACT_SPLIT | SRZ_UNIFIED | SRZ_FUSED_CLEAR */
+  uint32_t flags; /* SRZ_EXACT_SPLIT | SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER */
   uint32_t _pad;
 } srz_frame;
 
@@ -103,7 +105,8 @@ typedef struct srz_stats {
   uint64_t n_culled;    /* rejected by the backface test (src/Rasterizer.cpp:203-205) */
   uint64_t pixel_tests; /* sum of bbox areas of the surviving triangles */
   uint64_t fragments;   /* (triangle,pixel) pairs that pass the coverage test */
-  uint64_t shaded;      /* of those, pairs that also pass the z-test in submission order */
+  uint64_t shaded;      /* of those, pairs that also pass the z-test in submission order (the reference's ordered walk;
+                         * a call that asks for stats runs the ordered rasteriser once more on a scratch copy) */
   uint64_t visible;     /* pixels whose final owner is a triangle of this call */
   uint64_t visible_textured; /* of those, pixels whose owner's shader fetches the texture (B_tex of the roofline) */
 } srz_stats;
@@ -235,9 +238,6 @@ int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4);
 int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
-/* diagnostic only: arm!=0 allocates a per-tile timeline filled by the next srz_frameset_stats; arm==0 copies it out
- * (4 x u64 per tile: start, end in 100 MHz ticks, HW_ID, 8x8 blocks) */
-int srz_debug_timeline(srz_ctx *ctx, uint64_t *out, size_t n_tiles, int arm);
 
 #ifdef __cplusplus
 }

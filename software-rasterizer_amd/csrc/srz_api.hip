@@ -41,8 +41,6 @@ struct srz_ctx {
   uint64_t tex_version = 1;
   int acc_launches = 0;
   unsigned long long dbg[ST_COUNT] = {};
-  unsigned long long *d_timeline = nullptr; // diagnostic buffer (srz_debug_timeline)
-  size_t timeline_cap = 0;
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
   hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
@@ -70,10 +68,18 @@ struct srz_frameset {
   uint16_t *d_tri_batch = nullptr;
   BatchDesc *d_batches = nullptr;
   srz_light *d_lights = nullptr;
-  RasterRec *d_band_recs = nullptr;
-  uint32_t *d_band_count = nullptr;
-  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_tile_mask = nullptr, *d_chunk_rows = nullptr;
-  uint32_t mask_words = 0;
+  // per-tile triangle lists: records in a pool of n_sub sub-pools (srz_device.h, RenderArgs); every render reports what
+  // it asked of each sub-pool (h_pool_heads, copied back asynchronously), and a render that finds the previous demand
+  // above the capacity grows the pool first — so the memory is O(triangle-tile pairs), not O(bands x triangles)
+  RasterRec *d_pool = nullptr;
+  uint32_t pool_sub_cap = 0, pool_n_sub = 1;
+  uint32_t *d_pool_heads = nullptr, *h_pool_heads = nullptr;
+  hipEvent_t pool_ev = nullptr;
+  bool pool_pending = false;
+  uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_slow_list = nullptr, *d_slow_count = nullptr;
+  uint32_t *d_redo_list = nullptr; // (its counter is d_slow_count[1])
+  bool any_fast = false, any_generic = true; // which builds of k_shade the frames need (classify_frames)
+  uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
   // scenesets keep everything srz_sceneset_update rewrites in ONE device block [FrameDesc | lights | DrawDesc] that is
@@ -120,6 +126,21 @@ void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &
   local_rows = world == 1 ? (uint32_t)height : per_rank * BAND;
 }
 
+// Which frames can be shaded by k_shade's FAST build: exactly 2 lights, p == 150 (Shader::p as the reference ships it,
+// src/Shader.cpp:10) and only NORMAL / TEXTURE / PHONG batches.  Sets FD_FAST_SHADE in the host copies of the descriptors.
+void classify_frames(srz_frameset *fs) {
+  fs->any_fast = false, fs->any_generic = false;
+  for (FrameDesc &d : fs->h_frames) {
+    bool fast = d.n_lights == 2u && d.p == 150.0f;
+    for (uint32_t b = 0; fast && b < d.n_batches; ++b) {
+      const int sh = fs->h_batches[d.batch_off + b].shader;
+      fast = sh == SRZ_SHADER_NORMAL || sh == SRZ_SHADER_TEXTURE || sh == SRZ_SHADER_PHONG;
+    }
+    d.flags = (d.flags & ~FD_FAST_SHADE) | (fast ? FD_FAST_SHADE : 0u);
+    (fast ? fs->any_fast : fs->any_generic) = true;
+  }
+}
+
 void free_frameset_buffers(srz_frameset *fs) {
   for (int i = 0; i < srz_frameset::STAGE_RING; ++i) {
     if (fs->h_stage[i]) (void)hipHostFree(fs->h_stage[i]);
@@ -135,15 +156,21 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_tri_batch);
   (void)hipFree(fs->d_batches);
   (void)hipFree(fs->d_lights);
-  (void)hipFree(fs->d_band_recs);
+  (void)hipFree(fs->d_pool);
+  (void)hipFree(fs->d_pool_heads);
+  if (fs->h_pool_heads) (void)hipHostFree(fs->h_pool_heads);
+  if (fs->pool_ev) (void)hipEventDestroy(fs->pool_ev);
+  (void)hipFree(fs->d_tile_cnt);
+  (void)hipFree(fs->d_tile_off);
+  (void)hipFree(fs->d_slow_list);
+  (void)hipFree(fs->d_slow_count);
+  (void)hipFree(fs->d_redo_list);
   (void)hipFree(fs->d_vis);
   (void)hipFree(fs->d_worklist);
   (void)hipFree(fs->d_work_count);
-  (void)hipFree(fs->d_tile_mask);
   (void)hipFree(fs->d_chunk_rows);
   (void)hipFree(fs->d_sdesc);
   (void)hipFree(fs->d_draws);
-  (void)hipFree(fs->d_band_count);
 }
 
 RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, uint32_t flags_or) {
@@ -156,13 +183,21 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.batches = fs->d_batches;
   a.lights = fs->d_lights;
   a.tex = ctx->d_tex;
-  a.band_recs = fs->d_band_recs;
+  a.pool = fs->d_pool;
+  a.pool_heads = fs->d_pool_heads;
+  a.pool_sub_cap = fs->pool_sub_cap;
+  a.pool_sub_mask = fs->pool_n_sub - 1u;
+  a.tile_cnt = fs->d_tile_cnt;
+  a.tile_off = fs->d_tile_off;
+  a.slow_list = fs->d_slow_list;
+  a.slow_count = fs->d_slow_count;
+  a.redo_list = fs->d_redo_list;
+  a.redo_count = fs->d_slow_count + 1;
+  a.force_ordered = 0, a.force_generic = 0, a.any_generic = fs->any_generic ? 1u : 0u;
   a.sdesc = fs->d_sdesc;
   a.vis = fs->d_vis;
   a.worklist = fs->d_worklist;
   a.work_count = fs->d_work_count;
-  a.tile_mask = fs->d_tile_mask;
-  a.mask_words = fs->mask_words;
   // k_shade lanes per frame: >= 128 (one or two tiles per virtual workgroup at 1024^2), and at least 4 virtual
   // workgroups per physical one when the batch has few frames
   static const uint32_t split = getenv("SRZ_SHADE_SPLIT") ? (uint32_t)atoi(getenv("SRZ_SHADE_SPLIT")) : 0u;
@@ -171,7 +206,6 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.tiles_x = fs->tiles_x;
   a.n_local_bands = fs->n_local_bands;
   a.n_frames = (uint32_t)fs->n_frames;
-  a.band_count = fs->d_band_count;
   a.out = d_out;
   a.local_rows = fs->local_rows;
   a.frame_stride = 4ull * fs->local_rows * (uint64_t)fs->width;
@@ -179,7 +213,6 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.shard_world = fs->shard_world;
   a.flags_or = flags_or;
   a.stats = ctx->d_stats;
-  a.timeline = nullptr;
   return a;
 }
 
@@ -233,8 +266,24 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipMemcpy(fs->d_sdesc, h.data(), sizeof(ShadeDescG) * h.size(), hipMemcpyHostToDevice));
     fs->sdesc_version = ctx->tex_version;
   }
+  // the record pool follows what the previous render asked for (read back asynchronously): growing is rare and the one
+  // place where a render waits for the device
+  if (fs->pool_pending && hipEventQuery(fs->pool_ev) == hipSuccess) {
+    fs->pool_pending = false;
+    uint32_t need = 0;
+    for (uint32_t i = 0; i < fs->pool_n_sub; ++i) need = std::max(need, fs->h_pool_heads[i]);
+    if (need > fs->pool_sub_cap) {
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      const uint64_t cap = (uint64_t)need + need / 4u + 64u;
+      if (cap * fs->pool_n_sub >= 0xffffffffull) return fail(ctx, SRZ_E_NOMEM, "tile lists exceed 2^32 records; split the batch");
+      RasterRec *p = nullptr;
+      HIP_TRY(ctx, hipMalloc(&p, sizeof(RasterRec) * cap * fs->pool_n_sub));
+      (void)hipFree(fs->d_pool);
+      fs->d_pool = p, fs->pool_sub_cap = (uint32_t)cap;
+    }
+  }
   RenderArgs a = make_args(ctx, fs, d_out, flags_or);
-  a.timeline = ctx->d_timeline; // null unless armed by srz_debug_timeline
+  a.force_ordered = a.force_generic = stats ? 1u : 0u; // the counters are those of the reference's ordered walk
   EventPair ep{};
   bool timed = ctx->timing && !stats && ctx->ev_used.size() < 65536;
   if (timed) {
@@ -243,16 +292,22 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipEventRecord(ep.t0, s));
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
-  if (fs->max_tris == 0) HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * fs->n_frames, s)); // (else: k_setup)
+  if (fs->max_tris == 0) { // (else: k_setup resets the per-render counters)
+    HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * fs->n_frames, s));
+    HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * fs->pool_n_sub, s));
+    HIP_TRY(ctx, hipMemsetAsync(fs->d_slow_count, 0, 2 * sizeof(uint32_t), s));
+  }
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
-  launch_bands(a, fs->d_band_recs, fs->d_band_count, fs->n_frames, fs->n_local_bands, fs->max_tris, s);
+  launch_bin(a, fs->n_frames, s);
+  HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * fs->pool_n_sub, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipEventRecord(fs->pool_ev, s));
+  fs->pool_pending = true;
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in line (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
-  const bool skip_clear = (flags_or & 0x2000u) != 0; // dev probe only (SRZ_DEBUG_FLAGS): leaves untouched tiles unwritten
-  const bool side = any_fused && fs->max_tiles >= 8192 && !skip_clear;
+  const bool side = any_fused && fs->max_tiles >= 8192;
   unsigned ev = 0;
   if (side) {
     if (!ctx->stream2) {
@@ -267,12 +322,12 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork[ev], 0));
     launch_clear(a, fs->max_tiles, true, ctx->stream2);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], ctx->stream2));
-  } else if (any_fused && !skip_clear) {
+  } else if (any_fused) {
     launch_clear(a, fs->max_tiles, false, s);
   }
-  launch_raster(a, fs->n_frames, fs->n_local_bands, fs->width, stats, s);
+  launch_raster(a, fs->n_frames, stats, s);
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
-  launch_shade(a, fs->max_tiles, stats, s);
+  launch_shade(a, fs->max_tiles, stats, fs->any_fast, fs->any_generic, s);
   if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
@@ -280,6 +335,23 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   }
   HIP_TRY(ctx, hipGetLastError());
   return SRZ_OK;
+}
+
+int read_stats(srz_ctx *ctx, hipStream_t s, srz_stats *st);
+
+// The counters of srz_stats are those of the reference's ORDERED walk ("shaded" = fragments that pass the z-test when
+// their triangle is drawn), which the order-independent rasteriser does not produce.  A draw that asks for them runs the
+// counting kernels (ordered rasteriser) once more on a scratch copy of the framebuffer the draw starts from.
+int stats_pass(srz_ctx *ctx, srz_frameset *fs, const float *d_start, uint32_t flags_or, hipStream_t s, srz_stats *st) {
+  const size_t bytes = (size_t)fs->n_frames * 4u * fs->local_rows * (size_t)fs->width * sizeof(float);
+  float *d_tmp = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_tmp, bytes));
+  hipError_t e = d_start ? hipMemcpyAsync(d_tmp, d_start, bytes, hipMemcpyDeviceToDevice, s) : hipSuccess;
+  int rc = e == hipSuccess ? render_impl(ctx, fs, d_tmp, flags_or, s, true) : fail(ctx, SRZ_E_NODEVICE, hipGetErrorString(e));
+  if (rc == SRZ_OK) rc = read_stats(ctx, s, st); // (synchronises s)
+  else (void)hipStreamSynchronize(s);
+  (void)hipFree(d_tmp);
+  return rc;
 }
 
 int read_stats(srz_ctx *ctx, hipStream_t s, srz_stats *st) {
@@ -413,7 +485,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     delete fs;
     return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: frames x tiles exceeds the launch grid limit; split the batch");
   }
-  uint64_t tri_off = 0, light_off = 0, batch_off = 0, list_off = 0, count_off = 0;
+  uint64_t tri_off = 0, light_off = 0, batch_off = 0;
   for (int f = 0; f < n_frames; ++f) {
     const srz_frame &fr = frames[f];
     auto bad = [&](const char *m) {
@@ -431,7 +503,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     d.p = fr.p, d.kh = fr.kh, d.kn = fr.kn;
     d.n_lights = fr.n_lights, d.light_off = (uint32_t)light_off;
     d.tri_off = (uint32_t)tri_off, d.n_batches = fr.n_batches, d.batch_off = (uint32_t)batch_off;
-    d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR);
+    d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER);
     uint64_t nt = 0;
     for (uint32_t b = 0; b < fr.n_batches; ++b) {
       const srz_batch &sb = fr.batches[b];
@@ -443,13 +515,13 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     if (tri_off + nt > 0xfffffff0ull || nt >= 0x7fffffffull) return bad("too many triangles");
     d.n_tris = (uint32_t)nt;
     d.n_local_bands = fs->n_local_bands;
-    d.list_off = list_off, d.count_off = (uint32_t)count_off;
+    d.chunk_off = (uint32_t)(tri_off / 64u) + (uint32_t)f; // (every frame's chunk words start on a word of their own)
     fs->h_frames.push_back(d);
     fs->max_tris = std::max(fs->max_tris, d.n_tris);
     tri_off += nt, light_off += fr.n_lights, batch_off += fr.n_batches;
-    list_off += (uint64_t)fs->n_local_bands * nt, count_off += fs->n_local_bands;
   }
   fs->total_tris = tri_off, fs->total_lights = light_off;
+  classify_frames(fs);
 
   // stage host copies (pinned not needed: one-time upload)
   std::vector<srz_tri> h_tris(copy_tris ? (size_t)tri_off : 0);
@@ -479,14 +551,28 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));
   fs->max_tiles = (uint32_t)n_frames * fs->n_local_bands * fs->tiles_x;
-  FS_TRY(dev_alloc((void **)&fs->d_band_recs, sizeof(RasterRec) * (list_off + 64))); // + one speculative chunk (k_raster)
+  {  // record pool: one sub-pool per ~128 binning workgroups (their bump allocators are single addresses); first guess
+     // 4 records per triangle — the renders' own demand corrects it (render_impl)
+    const uint64_t n_wgs = (uint64_t)((n_frames + 7) / 8 * 8) * fs->n_local_bands;
+    uint32_t n_sub = 1;
+    while (n_sub < 64u && (uint64_t)n_sub * 256u <= n_wgs) n_sub *= 2u;
+    fs->pool_n_sub = n_sub;
+    const uint64_t cap = std::min<uint64_t>((4ull * tri_off + 4096u) / n_sub + 64u, 0xfffffff0ull / n_sub);
+    fs->pool_sub_cap = (uint32_t)cap;
+    FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(RasterRec) * cap * n_sub));
+    FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * 64));
+    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * 64, hipHostMallocDefault));
+    FS_TRY(hipEventCreateWithFlags(&fs->pool_ev, hipEventDisableTiming));
+    FS_TRY(dev_alloc((void **)&fs->d_tile_cnt, sizeof(uint32_t) * fs->max_tiles));
+    FS_TRY(dev_alloc((void **)&fs->d_tile_off, sizeof(uint32_t) * fs->max_tiles));
+    FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));
+    FS_TRY(dev_alloc((void **)&fs->d_slow_count, 2 * sizeof(uint32_t)));
+    FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint32_t) * fs->max_tiles));
+  }
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
   FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
   FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * n_frames));
-  fs->mask_words = (fs->tiles_x + 31u) / 32u;
-  FS_TRY(dev_alloc((void **)&fs->d_tile_mask, sizeof(uint32_t) * (size_t)n_frames * fs->n_local_bands * fs->mask_words));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
-  FS_TRY(dev_alloc((void **)&fs->d_band_count, sizeof(uint32_t) * count_off));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
   if (tri_off) {
     if (copy_tris) FS_TRY(hipMemcpy(fs->d_tris, h_tris.data(), sizeof(srz_tri) * tri_off, hipMemcpyHostToDevice));
@@ -626,7 +712,7 @@ int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *f
         (sf.n_lights && !sf.lights) || (sf.n_draws && !sf.draws))
       return fail(ctx, SRZ_E_INVALID, "srz_sceneset_update: structure changed");
     std::memcpy(d.eye, sf.eye, sizeof d.eye), std::memcpy(d.ka, sf.ka, sizeof d.ka), std::memcpy(d.ks, sf.ks, sizeof d.ks);
-    d.p = sf.p, d.kh = sf.kh, d.kn = sf.kn, d.flags = sf.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR);
+    d.p = sf.p, d.kh = sf.kh, d.kn = sf.kn, d.flags = sf.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER);
     if (sf.n_lights) std::memcpy(&h_lights[d.light_off], sf.lights, sizeof(srz_light) * sf.n_lights);
     for (uint32_t k = 0; k < sf.n_draws; ++k, ++di, ++bi) {
       const srz_mesh_draw &dr = sf.draws[k];
@@ -641,6 +727,7 @@ int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *f
       if (b.shader != dr.shader || b.tex_id != dr.tex_id) b.shader = dr.shader, b.tex_id = dr.tex_id, batches_changed = true;
     }
   }
+  classify_frames(fs);
   // one asynchronous copy on the context's stream: ordered after every render already submitted there (which may still
   // be reading the descriptors) and before the next one.  Renders submitted on OTHER streams are the caller's to order.
   const unsigned slot = fs->stage_next++ % srz_frameset::STAGE_RING;
@@ -722,9 +809,10 @@ int srz_target_draw(srz_ctx *ctx, srz_target *t, int primitive, srz_frameset *fs
     return fail(ctx, SRZ_E_INVALID, "srz_target_draw: needs an unsharded 1-frame set of the target's size");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t flags = t->pending_clear ? SRZ_FUSED_CLEAR : 0u;
-  t->pending_clear = false;
-  int rc = render_impl(ctx, fs, t->d_planes, flags, ctx->stream, stats != nullptr);
-  if (rc == SRZ_OK && stats) rc = read_stats(ctx, ctx->stream, stats);
+  int rc = SRZ_OK;
+  if (stats) rc = stats_pass(ctx, fs, t->pending_clear ? nullptr : t->d_planes, flags, ctx->stream, stats);
+  if (rc == SRZ_OK) rc = render_impl(ctx, fs, t->d_planes, flags, ctx->stream, false);
+  if (rc == SRZ_OK) t->pending_clear = false; // (a failed draw leaves the pending clear(Color|Depth) in place)
   return rc;
 }
 
@@ -788,9 +876,7 @@ int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_
   if (((uintptr_t)d_out & 15u) != 0) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: output must be 16-byte aligned");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  // bits 8..15 are kernel-ablation switches for the dev probes (tests/perf_probe.py); honoured only under SRZ_DEBUG_FLAGS
-  static const bool dbg = getenv("SRZ_DEBUG_FLAGS") != nullptr;
-  flags &= (SRZ_UNIFIED | SRZ_FUSED_CLEAR) | (dbg ? 0xff00u : 0u);
+  flags &= SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER;
   return render_impl(ctx, fs, (float *)d_out, flags, s, false);
 }
 
@@ -888,23 +974,6 @@ int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3) {
   return SRZ_OK;
 }
 
-/* diagnostic: per-tile {start,end (100 MHz wall clock), HW_ID, blocks} of the next stats run; cap = tiles */
-int srz_debug_timeline(srz_ctx *ctx, uint64_t *out, size_t n_tiles, int arm) {
-  if (!ctx) return SRZ_E_INVALID;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (arm) {
-    (void)hipFree(ctx->d_timeline);
-    ctx->d_timeline = nullptr;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_timeline, n_tiles * 32));
-    HIP_TRY(ctx, hipMemset(ctx->d_timeline, 0, n_tiles * 32));
-    ctx->timeline_cap = n_tiles;
-    return SRZ_OK;
-  }
-  if (!ctx->d_timeline || !out || n_tiles > ctx->timeline_cap) return SRZ_E_INVALID;
-  HIP_TRY(ctx, hipMemcpy(out, ctx->d_timeline, n_tiles * 32, hipMemcpyDeviceToHost));
-  return SRZ_OK;
-}
-
 /* diagnostic: raw counters of the last STATS run (incl. per-phase cycle sums); not part of the stable ABI */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n) {
   if (!ctx || !out) return SRZ_E_INVALID;
@@ -944,8 +1013,8 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
   if (!fused)
     for (int p = 0; p < 4 && e == hipSuccess; ++p) e = hipMemcpyAsync(d_out + p * plane, host[p], pb, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    rc = render_impl(ctx, fs, d_out, 0, s, stats != nullptr);
-    if (rc == SRZ_OK && stats) rc = read_stats(ctx, s, stats);
+    if (stats) rc = stats_pass(ctx, fs, fused ? nullptr : d_out, 0, s, stats);
+    if (rc == SRZ_OK) rc = render_impl(ctx, fs, d_out, 0, s, false);
   }
   for (int p = 0; p < 4 && e == hipSuccess && rc == SRZ_OK; ++p)
     e = hipMemcpyAsync(host[p], d_out + p * plane, pb, hipMemcpyDeviceToHost, s);
@@ -991,8 +1060,10 @@ int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_f
     if (!(frames[f].flags & SRZ_FUSED_CLEAR))
       e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_out) + fb * f, planes[f], fb, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    rc = render_impl(ctx, fs, d_out, 0, s, stats != nullptr);
-    if (rc == SRZ_OK && stats) rc = read_stats(ctx, s, stats);
+    if (stats) { // (frames with SRZ_FUSED_CLEAR ignore what the scratch copy holds)
+      rc = stats_pass(ctx, fs, d_out, 0, s, stats);
+    }
+    if (rc == SRZ_OK) rc = render_impl(ctx, fs, d_out, 0, s, false);
   }
   for (int f = 0; f < n_frames && e == hipSuccess && rc == SRZ_OK; ++f)
     e = hipMemcpyAsync(planes[f], reinterpret_cast<uint8_t *>(d_out) + fb * f, fb, hipMemcpyDeviceToHost, s);

@@ -10,16 +10,17 @@ namespace srz {
 
 constexpr int TILE = 32;             // one wavefront owns one 32x32-pixel tile (its z + owner planes live in LDS)
 constexpr int BAND = 32;             // band = one row of tiles; the unit of multi-GPU sharding and of binning
-constexpr int RASTER_WAVES = 1;      // k_raster: ONE wave (= one tile) per workgroup, so a long tile never pins the LDS /
-                                     // wave slots of finished neighbours and the dispatcher load-balances tile by tile
-// LDS row stride of k_raster's tile planes in dwords.  40 makes every 8x8 / 16x4 / 4x16 block bank-conflict-free but costs
-// 10 KiB per wave = 16 waves per CU; the unpadded 32 takes 4-way conflicts on 8x8 blocks and fits 20 waves per CU, which
-// is worth more (measured: k_raster -4.5 %; 36 = 17 waves: no gain)
-#ifndef SRZ_LDS_STRIDE
-#define SRZ_LDS_STRIDE 32
-#endif
-constexpr int LDS_STRIDE = SRZ_LDS_STRIDE;
+// k_raster: ONE wave (= one tile) per workgroup, so a long tile never pins the LDS / wave slots of finished neighbours and
+// the dispatcher load-balances tile by tile.  Its tile state is one 64-bit key per pixel; rows are padded to 33 keys
+// (264 B): lanes that hit the same column of consecutive rows land in different bank pairs, and the 33rd key of every
+// row doubles as scratch for the item expansion.  8448 B per wave = 19 waves per CU.
+constexpr int KEY_STRIDE = TILE + 1;
+// LDS row stride (dwords) of the ORDERED rasteriser's z / owner planes (k_raster_slow)
+constexpr int LDS_STRIDE = 32;
 constexpr uint32_t NO_TRI = 0xffffffffu;
+// FrameDesc::flags, internal (set by the host): 2 lights, p == 150, every batch NORMAL / TEXTURE / PHONG → k_shade's FAST build
+constexpr uint32_t FD_FAST_SHADE = 0x100u;
+constexpr uint32_t UNLISTED = 0xffffffffu; // tile_off of a tile whose list did not fit the record pool
 constexpr int MAX_TEX = 64;
 constexpr int MAX_MESH = 256;
 
@@ -29,13 +30,16 @@ struct __attribute__((aligned(8))) BBox {
   int16_t sx, sy, ex, ey;
 };
 
-// One entry of a band's triangle list: everything the coverage/z pass needs, gathered once by k_bands so that the
-// tile waves read their work with ONE level of (prefetchable, coalesced) loads.
+// One entry of a TILE's triangle list: everything the coverage/z pass needs, gathered once by k_bin so that the tile
+// waves read their work with ONE level of coalesced loads (one 64-byte line per entry).
 struct __attribute__((aligned(16))) RasterRec {
   float ax, ay, z0, bx, by, z1, cx, cy, z2;
   uint32_t bbx; // sx | sy << 16
   uint32_t bby; // ex | ey << 16
-  uint32_t idx; // triangle index inside the frame
+  uint32_t idx; // triangle index inside the frame (= submission order)
+  float v_inv;  // 1 / fmsub(ABx,ACy,ACx*ABy): "V" columns (src/Rasterizer.cpp:111-112)
+  float s_area; // ABx*ACy - ABy*ACx: scalar-tail columns (src/Rasterizer.cpp:61)
+  uint32_t _pad[2];
 };
 
 // What the Shader object bound to a batch holds (type + texture), resolved on the host at render time
@@ -65,9 +69,7 @@ struct FrameDesc {
   uint32_t n_batches, batch_off; // into batches[]
   uint32_t flags;
   uint32_t n_local_bands;        // bands of this frame owned by this ctx
-  uint64_t list_off;             // into band_recs[] (entries): local band lb at list_off + lb * n_tris
-  uint32_t count_off;            // into band_count[]: local band lb at count_off + lb
-  uint32_t _pad;
+  uint32_t chunk_off;            // into chunk_rows[]: first 64-triangle chunk of this frame
 };
 
 struct BatchDesc {
@@ -94,13 +96,25 @@ struct RenderArgs {
   const srz_light *lights;
   const TexDesc *tex;
   const ShadeDescG *sdesc;       // per batch (indexed like batches[])
-  const RasterRec *band_recs;
-  const uint32_t *band_count;
+  // per-tile triangle lists, UNORDERED (the rasteriser's result does not depend on list order): records live in a pool
+  // of n_sub equal sub-pools with one bump allocator each; a (frame, band) workgroup of k_bin takes its band's records
+  // from sub-pool (workgroup id & sub_mask) in one allocation.  A band that does not fit is left UNLISTED: its tiles are
+  // rasterised by k_raster_slow straight from the frame's stream, and the host grows the pool before the next render.
+  RasterRec *pool;
+  uint32_t *pool_heads;          // [n_sub] records requested from each sub-pool by this render (zeroed by k_setup)
+  uint32_t pool_sub_cap, pool_sub_mask;
+  uint32_t *tile_cnt;            // [frame][local band][tiles_x] entries in the tile's list (0: k_clear's tile)
+  uint32_t *tile_off;            // [frame][local band][tiles_x] first record in pool[], or UNLISTED
+  uint32_t *slow_list;           // tiles (frame * tiles_per_frame + tile) left to the ordered rasteriser
+  uint32_t *slow_count;
+  uint32_t force_ordered;        // every touched tile goes to k_raster_slow (SRZ_ORDERED_RASTER, counting runs)
+  uint32_t force_generic;        // every frame is shaded by the generic build of k_shade (counting runs)
+  uint32_t any_generic;          // some frame is not FD_FAST_SHADE (else the generic build only serves redo_list)
+  uint32_t *redo_list;           // tiles (frame * tiles_per_frame + tile) the FAST build of k_shade hands to the generic one
+  uint32_t *redo_count;
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
   uint32_t *worklist;            // [frame][tiles per frame]: tiles (lb*tiles_x + tx) that have an owner, in arrival order
   uint32_t *work_count;          // [frame] entries in the frame's list (zeroed by k_setup, bumped by k_raster)
-  uint32_t *tile_mask;           // [frame][local band][mask_words]: bit tx set = some bbox of the band list overlaps tile tx
-  uint32_t mask_words;           // (tiles_x + 31) / 32
   uint32_t shade_split;          // k_shade: virtual workgroups ("lanes") per frame
   uint32_t tiles_x, n_local_bands, n_frames;
   float *out;             // [frame][4][local_rows][width]
@@ -114,11 +128,10 @@ struct RenderArgs {
 
 void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, hipStream_t s);
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
-void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
-                  uint32_t max_tris, hipStream_t s);
-void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s);
+void launch_bin(const RenderArgs &a, int n_frames, hipStream_t s);
+void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
-void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s);
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s);
 void launch_verify_fastmath(unsigned long long *d_out4, hipStream_t s);

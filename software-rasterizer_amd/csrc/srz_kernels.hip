@@ -6,18 +6,18 @@
 //
 //   k_vertex  one thread per face          (optional) the vertex stage, Scene::loadTriangleStream: meshes + matrices → srz_tri
 //   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox record
-//   k_bands   one WORKGROUP per 32-row band ordered compaction of the BBox stream (count / scan / fill, hit masks in LDS) →
-//                                          per-band list of 48-byte RasterRec (positions + bbox + index), submission order
-//                                          preserved by construction: no atomics, no sort; + per-band mask of the tiles any
-//                                          listed bbox reaches
-//   k_clear   ~160 persistent workgroups   on a second stream beside k_raster / k_shade: the fused clear of every tile no
+//   k_bin     one WORKGROUP per 32-row band count / scan / fill of the BBox stream into UNORDERED per-tile lists of 64-byte
+//                                          RasterRec (positions + bbox + index + the per-triangle constants of both coverage
+//                                          tests), LDS atomics only; records come from a pool sized by what renders need
+//   k_clear   ~64 persistent workgroups    on a second stream beside k_raster / k_shade: the fused clear of every tile no
 //                                          bbox reaches (16-byte non-temporal stores of +inf / 0), throttled by its grid
-//   k_raster  one WAVE per touched tile    VISIBILITY: tile z-buffer + owner-id planes in LDS; walks its band's list in
-//                                          order (next chunk prefetched), per triangle the 64 lanes sweep pixel blocks of
-//                                          bbox∩tile, run the coverage + z-test with the reference's per-column semantics
-//                                          and update LDS (a wave's LDS ops are ordered → "last writer in submission order
-//                                          wins" needs no lock).  Touched tiles nobody owns leave as the fused clear; owned
-//                                          tiles write z + owner ids and append themselves to their frame's work list.
+//   k_raster  one WAVE per touched tile    VISIBILITY, order-independent: one 64-bit key (depth | tie-break) per pixel in
+//                                          LDS, every fragment is a ds_min_u64; the tile's (triangle, pixel) candidates are
+//                                          flattened into items (8 pixels of a bbox row / one scalar-tail pixel) and dealt
+//                                          densely to the 64 lanes.  Touched tiles nobody owns leave as the fused clear;
+//                                          owned tiles write z + owner ids and append themselves to their frame's work list.
+//   k_raster_slow  one wave per listed tile the reference's ORDERED algorithm for what the keys cannot express (NaN / ±0
+//                                          depths), for bands that did not fit the pool, and for counting runs.
 //   k_shade   one WORKGROUP per owned tile VISIBILITY-FIRST SHADING: each pixel's final owner is shaded exactly once (the
 //                                          reference's shaders are pure functions of (triangle,pixel) and its write is an
 //                                          overwrite), pixels compacted by semantics class into dense 64-lane chunks,
@@ -62,6 +62,8 @@ __device__ __forceinline__ float fmaf_(float a, float b, float c) { return __bui
 // range (k_verify_fastmath, run by tests/test_gpu_fastmath.py).  Operands outside the range (zero, denormal, huge,
 // inf, NaN) take the compiler's full IEEE path, so the functions are drop-in equal to `1.0f/x` and `sqrtf(x)`.
 __device__ __forceinline__ uint32_t f2u_(float f) { return __builtin_bit_cast(uint32_t, f); }
+// (by-value helpers: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
+__device__ __forceinline__ float u2f_(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ bool fast_range(float x) { return (((f2u_(x) >> 23) & 0xffu) - 27u) <= 200u; }
 __device__ __forceinline__ float rcp_core(float x) { // v_rcp_f32 + one Newton step
   float r = __builtin_amdgcn_rcpf(x);
@@ -194,6 +196,22 @@ __device__ __forceinline__ float pow_cr(float x, float p) {
   return (float)pow((double)x, (double)p);
 }
 
+// x^150 (the reference's Shader::p, src/Shader.cpp:10) as a fixed chain: the very multiplications pow_cr's loop performs
+// for n = 150 = 0b10010110, in the same order (r = x^2 · x^4 · x^16 · x^128), without the loop
+__device__ __forceinline__ float pow150_cr(float x) {
+  const double b1 = (double)x, b2 = b1 * b1, b4 = b2 * b2, b8 = b4 * b4, b16 = b8 * b8, b32 = b16 * b16, b64 = b32 * b32,
+               b128 = b64 * b64;
+  double r = b2 * b4;
+  r = r * b16;
+  r = r * b128;
+  return (float)r;
+}
+// Compile-time knowledge a shading variant may have (k_shade picks the variant per 64-pixel chunk, wave-uniformly):
+//   SH   >= 0: every pixel of the chunk uses shader type SH; -1: per-pixel type (sd.shader)
+//   L2P150   : the frame has exactly 2 lights and p == 150 (the reference's README scene and Shader::p default):
+//              the light loop is unrolled, the light constants sit in SGPRs and the exponent is the fixed chain
+template <bool L2P150> __device__ __forceinline__ float pow_frame(float x, float p) { return L2P150 ? pow150_cr(x) : pow_cr(x, p); }
+
 __device__ __forceinline__ int32_t cvt_rne_i32(float f) {
   if (!(f >= -2147483648.0f && f < 2147483648.0f)) return INT32_MIN;
   return (int32_t)__builtin_rintf(f);
@@ -279,6 +297,10 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) a.work_count[blockIdx.y] = 0u; // this frame's work list starts empty
+  if (blockIdx.x == 0 && blockIdx.y == 0) {                              // so do the record pool and the slow list
+    if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
+  }
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
   const int W = fd->width, H = fd->height;
   const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
@@ -321,11 +343,11 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
       n_culled++;
     }
     if (live) bbox_out[tri_off + t] = bb;
-    // rows spanned by the kept triangles of this 64-triangle chunk (= this wave's 64 consecutive t): lets k_bands skip
+    // rows spanned by the kept triangles of this 64-triangle chunk (= this wave's 64 consecutive t): lets k_bin skip
     // the chunks that cannot reach a band without reading their 64 bboxes
     int lo = keep ? (int)bb.sy : 0x7fff, hi = keep ? (int)bb.ey : -1;
     for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));
-    if ((threadIdx.x & 63) == 0) a.chunk_rows[tri_off / 64u + blockIdx.y + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+    if ((threadIdx.x & 63) == 0) a.chunk_rows[fd->chunk_off + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
   }
   if (STATS) {
     if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
@@ -335,152 +357,172 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
 }
 
 // ================================================================================================================
-// k_bands — one WORKGROUP of 16 waves per (frame, local band): ordered compaction of the triangles whose bbox touches
-// the band into the band's RasterRec list.  Submission order is preserved by construction (no atomics, no sort):
-//   pass 1  the 64-triangle chunks are dealt round-robin to the waves; each wave ballots its chunks and stores the
-//           per-chunk hit count in LDS
-//   scan    exclusive prefix over the chunk counts (wave 0)
-//   pass 2  each wave revisits its chunks; a hit's output slot = chunk offset + rank inside the chunk.  Hits are queued
-//           (index, slot) in LDS and flushed 64 at a time so that the gather of positions + bbox is one round trip of
-//           independent loads per 64 hits, written as 48-byte RasterRec.
-// Lists longer than BANDS_MAX_CHUNKS*64 triangles are handled in super-blocks with a running base.
+// Wave-level scans on the DPP crossbar (no LDS traffic): inclusive prefix over the 64 lanes.
+// row_shr:1,2,4,8 scan inside each row of 16 lanes (lanes without a source read the identity 0), row_bcast:15 / :31
+// carry the row totals into the rows behind.
 // ================================================================================================================
-constexpr int BANDS_MAX_WAVES = 16;
-constexpr int BANDS_MAX_CHUNKS = 2048; // chunk counters held in LDS per super-block (= 131072 triangles)
+#define SRZ_DPP(v, ctrl, rmask) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  v += SRZ_DPP(v, 0x111, 0xf), v += SRZ_DPP(v, 0x112, 0xf), v += SRZ_DPP(v, 0x114, 0xf), v += SRZ_DPP(v, 0x118, 0xf);
+  v += SRZ_DPP(v, 0x142, 0xa); // row_bcast:15 → rows 1 and 3
+  v += SRZ_DPP(v, 0x143, 0xc); // row_bcast:31 → rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+  v = max(v, SRZ_DPP(v, 0x111, 0xf)), v = max(v, SRZ_DPP(v, 0x112, 0xf)), v = max(v, SRZ_DPP(v, 0x114, 0xf));
+  v = max(v, SRZ_DPP(v, 0x118, 0xf));
+  v = max(v, SRZ_DPP(v, 0x142, 0xa));
+  v = max(v, SRZ_DPP(v, 0x143, 0xc));
+  return v;
+}
 
-// launched with 4..16 waves per workgroup (small streams do not pay for idle waves) and
-// dynamic LDS = (3 * chunks_cap + 256 * waves + 2 + mask_words) dwords:
-//   [hit masks (u64) | offsets | per-wave index/slot queues | total | tile mask]
-__global__ __launch_bounds__(64 * BANDS_MAX_WAVES) void k_bands(RenderArgs a, RasterRec *band_recs, uint32_t *band_count,
-                                                                uint32_t chunks_cap) {
+// ================================================================================================================
+// k_bin — one WORKGROUP per (frame, local band): the triangles whose bbox touches the band are appended to the lists
+// of the 32x32 tiles they overlap.  The rasteriser's result does not depend on the order of a tile's list (k_raster
+// resolves depth ties with the triangle index, not with the list position), so this is a plain count / scan / fill with
+// LDS atomics — no ordered compaction:
+//   pass 1  the 64-triangle chunks are dealt to the waves; a chunk whose row range (written by k_setup) misses the band
+//           is skipped without reading its bboxes; every hit bumps the LDS counter of each tile it overlaps
+//   scan    exclusive prefix over the tile counters (wave 0) = the band's layout; ONE global atomic takes the band's
+//           records from the sub-pool of this workgroup (k_raster_slow serves the tiles of a band that does not fit)
+//   pass 2  the hits are queued per wave and flushed 64 at a time: one round trip of independent gathers (positions +
+//           bbox) per 64 hits, the per-triangle constants of both coverage tests are computed once here, and every
+//           (triangle, tile) pair becomes one 64-byte record at pool[band base + tile offset + slot]
+// ================================================================================================================
+constexpr int BIN_WAVES = 4;
+// dynamic LDS = (3 * tiles_x + 128 * BIN_WAVES + 4) dwords: [count | offset | fill cursor] per tile, per-wave queues
+__global__ __launch_bounds__(64 * BIN_WAVES) void k_bin(RenderArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  const int BANDS_WAVES = (int)(blockDim.x >> 6);
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_dyn); // pass 1: hit mask of every chunk
-  uint32_t *s_off = s_dyn + 2 * chunks_cap;                                   // after the scan: exclusive offset per chunk
-  uint32_t *s_q = s_off + chunks_cap;
-  uint32_t &s_total = s_q[256 * BANDS_WAVES];
-  uint32_t *s_tmask = s_q + 256 * BANDS_WAVES + 2; // tiles of this band overlapped by some listed bbox
-  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
+  const uint32_t TX = a.tiles_x;
+  uint32_t *s_cnt = s_dyn, *s_off = s_dyn + TX, *s_fill = s_dyn + 2 * TX, *s_q = s_dyn + 3 * TX;
+  uint32_t *s_misc = s_q + 128 * BIN_WAVES; // [0] first record of the band in pool[] (or UNLISTED), [1] records of the band
+  // same XCD-aware decomposition as k_raster: workgroup i bins frame (i % 8) of its group of 8 frames, so a frame's
+  // records are written through the L2 of the XCD that will rasterise it
+  const uint32_t wg = blockIdx.x, xcd = wg & 7u, jj = wg >> 3;
+  const uint32_t frame = (jj / a.n_local_bands) * 8u + xcd, lb = jj % a.n_local_bands;
+  if (frame >= a.n_frames) return; // workgroup-uniform
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t lb = blockIdx.x;
-  if (lb >= fd->n_local_bands) return; // workgroup-uniform
-  for (uint32_t w = threadIdx.x; w < a.mask_words; w += blockDim.x) s_tmask[w] = 0u;
+  for (uint32_t w = threadIdx.x; w < 3 * TX; w += blockDim.x) s_dyn[w] = 0u;
   __syncthreads();
-  const int Wm1 = fd->width - 1;
   const uint32_t n_tris = fd->n_tris;
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
-  RasterRec *out = band_recs + fd->list_off + (uint64_t)lb * n_tris;
   const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
   const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
-  const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->tri_off / 64u + blockIdx.y;
-  uint32_t *qi = s_q + 256 * wave, *qp = qi + 128;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  auto flush = [&](uint32_t n) { // n <= 64 queued (index, slot) pairs → records
-    if ((uint32_t)lane < n) {
-      const uint32_t t = qi[lane], pos = qp[lane];
-      const u32x2 r = bbox[t];
-      const SRZ_CAS float *p = &tris[t].pos[0][0];
-      RasterRec rec;
-      rec.ax = p[0], rec.ay = p[1], rec.z0 = p[2], rec.bx = p[3], rec.by = p[4], rec.z1 = p[5];
-      rec.cx = p[6], rec.cy = p[7], rec.z2 = p[8];
-      rec.bbx = r.x, rec.bby = r.y, rec.idx = t;
-      out[pos] = rec;
-      const int tlo = max((int)(int16_t)(r.x & 0xffff), 0) >> 5, thi = min((int)(int16_t)(r.y & 0xffff), Wm1) >> 5;
-      for (int w = tlo >> 5; w <= (thi >> 5); ++w) { // (one word unless the bbox straddles a 1024-pixel boundary)
-        const int b0 = max(tlo - w * 32, 0), b1 = min(thi - w * 32, 31);
-        if (b0 <= b1) atomicOr(&s_tmask[w], (0xffffffffu >> (31 - b1)) & (0xffffffffu << b0));
-      }
-    }
-  };
+  const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->chunk_off;
   const uint32_t n_chunks = (n_tris + 63) / 64;
-  uint32_t base = 0; // records written by earlier super-blocks
-  for (uint32_t sb = 0; sb < n_chunks; sb += chunks_cap) {
-    const uint32_t nc = min(chunks_cap, n_chunks - sb);
-    // ---- pass 1: per-chunk hit counts.  A wave first tests the row ranges of 64 chunks at once (one word per chunk,
-    //      written by k_setup) and ballots the bboxes only of the chunks that can reach this band -----------------------
-    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < nc; c0 += 64u * (uint32_t)BANDS_WAVES) {
+  uint32_t *qi = s_q + 128 * wave;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  // walks the chunks of this wave and calls fn(chunk, hit, bbox words) for every chunk that can reach the band, with the
+  // bbox loads of four candidate chunks in flight together (the walk is latency-bound, not bandwidth-bound)
+  auto walk = [&](auto &&fn) {
+    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_chunks; c0 += 64u * (uint32_t)BIN_WAVES) {
       bool cand = false;
       const uint32_t c = c0 + (uint32_t)lane;
-      if (c < nc) {
-        const uint32_t r = chunk_rows[sb + c];
+      if (c < n_chunks) {
+        const uint32_t r = chunk_rows[c];
         cand = (int)(int16_t)(r & 0xffffu) <= y1 && (int)(int16_t)(r >> 16) >= y0;
-        if (!cand) s_mask[c] = 0ull, s_off[c] = 0u;
       }
       unsigned long long mc = __ballot(cand);
-      while (mc) { // four candidates per step: their bbox loads are issued back to back (unconditionally, from a clamped
-                   // index) so that one round trip serves four chunks instead of one
-        uint32_t jj[4];
+      while (mc) {
+        uint32_t cj[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           ok[u] = mc != 0ull;
-          jj[u] = ok[u] ? (uint32_t)__builtin_ctzll(mc) : 0u;
+          cj[u] = ok[u] ? (uint32_t)__builtin_ctzll(mc) : 0u;
           mc &= mc - 1ull; // (0 stays 0)
         }
         u32x2 r[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = bbox[min((sb + c0 + jj[u]) * 64u + (uint32_t)lane, n_tris - 1u)];
+        for (int u = 0; u < 4; ++u) r[u] = bbox[min((c0 + cj[u]) * 64u + (uint32_t)lane, n_tris - 1u)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (!ok[u]) break; // wave-uniform
-          const bool live = (sb + c0 + jj[u]) * 64u + (uint32_t)lane < n_tris;
+          const uint32_t t = (c0 + cj[u]) * 64u + (uint32_t)lane;
           const int sx = (int16_t)(r[u].x & 0xffff), sy = (int16_t)(r[u].x >> 16), ex = (int16_t)(r[u].y & 0xffff), ey = (int16_t)(r[u].y >> 16);
-          const unsigned long long m = __ballot(live && sx <= ex && sy <= y1 && ey >= y0);
-          if (lane == 0) s_mask[c0 + jj[u]] = m, s_off[c0 + jj[u]] = (uint32_t)__popcll(m);
+          fn(t, t < n_tris && sx <= ex && sy <= y1 && ey >= y0, sx >> 5, ex >> 5); // (bbox is clamped to the frame by k_setup)
         }
       }
     }
-    __syncthreads();
-    // ---- scan (wave 0): exclusive prefix of the counts -------------------------------------------------------------
-    if (wave == 0) {
-      uint32_t run = base;
-      for (uint32_t c0 = 0; c0 < nc; c0 += 64) {
-        const uint32_t c = c0 + lane;
-        const uint32_t v = c < nc ? s_off[c] : 0u;
-        uint32_t incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint32_t up = __shfl_up(incl, o);
-          if (lane >= o) incl += up;
-        }
-        if (c < nc) s_off[c] = run + incl - v;
-        run += __shfl(incl, 63);
-      }
-      if (lane == 0) s_total = run;
+  };
+  // ---- pass 1: tile counts ---------------------------------------------------------------------------------------------
+  walk([&](uint32_t, bool hit, int tlo, int thi) {
+    if (hit)
+      for (int tx = tlo; tx <= thi; ++tx) atomicAdd(&s_cnt[tx], 1u);
+  });
+  __syncthreads();
+  // ---- scan (wave 0) + the band's allocation -----------------------------------------------------------------------------
+  if (wave == 0) {
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < TX; t0 += 64) {
+      const uint32_t tx = t0 + lane;
+      const uint32_t v = tx < TX ? s_cnt[tx] : 0u;
+      const uint32_t incl = wave_scan_add(v);
+      if (tx < TX) s_off[tx] = run + incl - v;
+      run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    __syncthreads();
-    // ---- pass 2: ordered fill ----------------------------------------------------------------------------------------
-    uint32_t nq = 0;
-    for (uint32_t c = (uint32_t)wave; c < nc; c += BANDS_WAVES) {
-      const unsigned long long m = s_mask[c];
-      if (m == 0ull) continue;
-      if ((m >> lane) & 1ull) {
-        const uint32_t k = nq + (uint32_t)__popcll(m & lt);
-        qi[k] = (sb + c) * 64 + lane;
-        qp[k] = s_off[c] + (uint32_t)__popcll(m & lt);
+    if (lane == 0) {
+      uint32_t base = 0;
+      if (run) {
+        const uint32_t sub = wg & a.pool_sub_mask;
+        const uint32_t start = atomicAdd(&a.pool_heads[sub], run); // (also the host's measure of what the render needed)
+        base = (start <= a.pool_sub_cap && run <= a.pool_sub_cap - start) ? sub * a.pool_sub_cap + start : UNLISTED;
       }
-      nq += (uint32_t)__popcll(m);
-      __builtin_amdgcn_wave_barrier();
-      if (nq >= 64) {
-        flush(64);
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t rest = nq - 64; // < 64
-        uint32_t mi = 0, mp = 0;
-        if ((uint32_t)lane < rest) mi = qi[64 + lane], mp = qp[64 + lane];
-        __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < rest) qi[lane] = mi, qp[lane] = mp;
-        nq = rest;
-        __builtin_amdgcn_wave_barrier();
-      }
+      s_misc[0] = base, s_misc[1] = run;
     }
-    if (nq) flush(nq);
-    base = s_total;
-    __syncthreads(); // s_off / s_total are reused by the next super-block
   }
-  if (threadIdx.x == 0) band_count[fd->count_off + lb] = base;
-  for (uint32_t w = threadIdx.x; w < a.mask_words; w += blockDim.x) // (the loop's last barrier ordered the atomics)
-    a.tile_mask[((size_t)blockIdx.y * a.n_local_bands + lb) * a.mask_words + w] = s_tmask[w];
+  __syncthreads();
+  const uint32_t base = s_misc[0];
+  {
+    uint32_t *tc = a.tile_cnt + ((size_t)frame * a.n_local_bands + lb) * TX, *to = a.tile_off + ((size_t)frame * a.n_local_bands + lb) * TX;
+    for (uint32_t tx = threadIdx.x; tx < TX; tx += blockDim.x) tc[tx] = s_cnt[tx], to[tx] = base == UNLISTED ? UNLISTED : base + s_off[tx];
+  }
+  if (base == UNLISTED || s_misc[1] == 0u) return; // workgroup-uniform
+  // ---- pass 2: fill ------------------------------------------------------------------------------------------------------
+  RasterRec *out = a.pool + base;
+  auto flush = [&](uint32_t n) { // n <= 64 queued triangles → one record per (triangle, tile) pair
+    if ((uint32_t)lane < n) {
+      const uint32_t t = qi[lane];
+      const u32x2 r = bbox[t];
+      const SRZ_CAS float *p = &tris[t].pos[0][0];
+      TriXY k;
+      k.ax = p[0], k.ay = p[1], k.z0 = p[2], k.bx = p[3], k.by = p[4], k.z1 = p[5], k.cx = p[6], k.cy = p[7], k.z2 = p[8];
+      BranchMath bm;
+      tri_consts(bm, k);
+      const f32x4 q0 = {k.ax, k.ay, k.z0, k.bx}, q1 = {k.by, k.z1, k.cx, k.cy};
+      const f32x4 q2 = {k.z2, u2f_(r.x), u2f_(r.y), u2f_(t)};
+      const f32x4 q3 = {k.v_inv, k.s_area, 0.f, 0.f};
+      const int tlo = (int)(int16_t)(r.x & 0xffff) >> 5, thi = (int)(int16_t)(r.y & 0xffff) >> 5;
+      for (int tx = tlo; tx <= thi; ++tx) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + s_off[tx] + atomicAdd(&s_fill[tx], 1u));
+        o[0] = q0, o[1] = q1, o[2] = q2, o[3] = q3;
+      }
+    }
+  };
+  uint32_t nq = 0;
+  walk([&](uint32_t t, bool hit, int, int) {
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    if (hit) qi[nq + (uint32_t)__popcll(m & lt)] = t;
+    nq += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (nq >= 64) {
+      flush(64);
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t rest = nq - 64; // < 64
+      uint32_t mi = 0;
+      if ((uint32_t)lane < rest) mi = qi[64 + lane];
+      __builtin_amdgcn_wave_barrier();
+      if ((uint32_t)lane < rest) qi[lane] = mi;
+      nq = rest;
+      __builtin_amdgcn_wave_barrier();
+    }
+  });
+  if (nq) flush(nq);
 }
 
 // ================================================================================================================
@@ -497,7 +539,7 @@ struct ShadeDesc { // what a batch's Shader object holds: type + texture (Shader
 };
 
 // BlinnPhong<__m256> for one light (include/shader/Shader.hpp:104-229)
-template <class M>
+template <class M, bool L2P150>
 __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz, const FrameK &K, float kdr, float kdg, float kdb,
                                               const SRZ_CAS srz_light *L, float px, float py, float pz, float &o0, float &o1,
                                               float &o2) {
@@ -510,22 +552,24 @@ __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz
   float nlx = lx, nly = ly, nlz = lz;
   v_normalized(m, nlx, nly, nlz);
   float cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
-  float cosT = pow_cr(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+  float cosT = pow_frame<L2P150>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
   o0 = kdr * fmaf_(K.ka[0], I0, fmaf_(d0 * kdr, cosA, (d0 * K.ks[0]) * cosT));
   o1 = kdg * fmaf_(K.ka[1], I1, fmaf_(d1 * kdg, cosA, (d1 * K.ks[1]) * cosT));
   o2 = kdb * fmaf_(K.ka[2], I2, fmaf_(d2 * kdb, cosA, (d2 * K.ks[2]) * cosT));
 }
 
 // Shader::applyFragmentShader SIMD overload + simd_*_impl (src/Shader.cpp:128-386); colour out in [0,255]
-template <class M>
+template <class M, int SH, bool L2P150>
 __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
+  const int shader = SH >= 0 ? SH : sd.shader;
+  const uint32_t n_lights = L2P150 ? 2u : K.n_lights;
   float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f;
-  if (sd.shader == SRZ_SHADER_NORMAL) {
+  if (shader == SRZ_SHADER_NORMAL) {
     c0 = (nx + 1.0f) * 0.5f, c1 = (ny + 1.0f) * 0.5f, c2 = (nz + 1.0f) * 0.5f;
-  } else if (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_PHONG) {
+  } else if (shader == SRZ_SHADER_TEXTURE || shader == SRZ_SHADER_PHONG) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
-    if (sd.shader == SRZ_SHADER_TEXTURE) {
+    if (shader == SRZ_SHADER_TEXTURE) {
       float tw = (float)sd.tw, th = (float)sd.th;
       u = u * tw, v = v * th;
       u = sse_max(0.0f, sse_min(u, tw - 1.0f));
@@ -537,9 +581,10 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
       kd2 = (float)((texel >> 16) & 0xffu) * inv255;
     }
     c0 = c1 = c2 = 0.0f;
-    for (uint32_t l = 0; l < K.n_lights; ++l) {
+#pragma unroll
+    for (uint32_t l = 0; l < n_lights; ++l) {
       float o0, o1, o2;
-      v_blinn_phong(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
+      v_blinn_phong<M, L2P150>(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
   }
@@ -565,7 +610,7 @@ __device__ __forceinline__ void s_texel(M &m, const ShadeDesc &sd, float u, floa
 }
 
 // Shader::BlinnPhong scalar (src/Shader.cpp:510-543); the two std::pow(x,2) and the sqrt are binary64 there
-template <class M>
+template <class M, bool L2P150>
 __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
                                               float kd0, float kd1, float kd2, const SRZ_CAS srz_light *L, float &o0, float &o1,
                                               float &o2) {
@@ -583,7 +628,7 @@ __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, f
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
   normalize3(m, hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
-  float pw = pow_cr(cosAlpha, K.p);
+  float pw = pow_frame<L2P150>(cosAlpha, K.p);
   o0 = ((K.ka[0] * I0 + (cosTheta * kd0) * d0) + (pw * K.ks[0]) * d0) * kd0;
   o1 = ((K.ka[1] * I1 + (cosTheta * kd1) * d1) + (pw * K.ks[1]) * d1) * kd1;
   o2 = ((K.ka[2] * I2 + (cosTheta * kd2) * d2) + (pw * K.ks[2]) * d2) * kd2;
@@ -610,28 +655,31 @@ __device__ __forceinline__ void s_bump_common(M &m, const ShadeDesc &sd, float n
 }
 
 // scalar applyFragmentShader + standard_*_impl + Tools::normalizedToRGB (src/Shader.cpp:547-640, src/Tools.cpp:94-104)
-template <class M>
+template <class M, int SH, bool L2P150>
 __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
+  const int shader = SH >= 0 ? SH : sd.shader;
+  const uint32_t n_lights = L2P150 ? 2u : K.n_lights;
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-  if (sd.shader == SRZ_SHADER_NORMAL) {
+  if (shader == SRZ_SHADER_NORMAL) {
     normalize3(m, nx, ny, nz);
     c0 = (nx + 1.0f) / 2.0f, c1 = (ny + 1.0f) / 2.0f, c2 = (nz + 1.0f) / 2.0f;
-  } else if (sd.shader >= SRZ_SHADER_TEXTURE && sd.shader <= SRZ_SHADER_BUMP) {
+  } else if (shader >= SRZ_SHADER_TEXTURE && shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
     float sx = px, sy = py, sz = pz, snx = nx, sny = ny, snz = nz;
-    if (sd.shader != SRZ_SHADER_PHONG) s_texel(m, sd, u, v, kd0, kd1, kd2);
-    if (sd.shader == SRZ_SHADER_BUMP) {
+    if (shader != SRZ_SHADER_PHONG) s_texel(m, sd, u, v, kd0, kd1, kd2);
+    if (shader == SRZ_SHADER_BUMP) {
       float on;
       s_bump_common(m, sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
-    } else if (sd.shader == SRZ_SHADER_DISPLACEMENT) {
+    } else if (shader == SRZ_SHADER_DISPLACEMENT) {
       float on;
       s_bump_common(m, sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
       sx = px + (K.kn * nx) * on, sy = py + (K.kn * ny) * on, sz = pz + (K.kn * nz) * on;
     }
-    for (uint32_t l = 0; l < K.n_lights; ++l) {
+#pragma unroll
+    for (uint32_t l = 0; l < n_lights; ++l) {
       float o0, o1, o2;
-      s_blinn_phong(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
+      s_blinn_phong<M, L2P150>(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
   }
@@ -671,7 +719,7 @@ template <class M> __device__ __forceinline__ void unpack_tri(M &m, const TriFet
   a.u0 = f.q4.z, a.v0 = f.q4.w, a.u1 = f.q5.x, a.v1 = f.q5.y, a.u2 = f.q5.z, a.v2 = f.q5.w;
 }
 // Shade pixel (x,y) of depth z, owner `f`, 8-wide ("V") semantics (src/Rasterizer.cpp:380-389)
-template <class M>
+template <class M, int SH = -1, bool L2P150 = false>
 __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
@@ -685,10 +733,10 @@ __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const Shade
   v_normalized(m, nx, ny, nz);
   float u = fmaf_(alpha, a.u0, fmaf_(beta, a.u1, gamma * a.u2));
   float v = fmaf_(alpha, a.v0, fmaf_(beta, a.v1, gamma * a.v2));
-  v_shade(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2); // zz: the depth k_raster stored (same operations)
+  v_shade<M, SH, L2P150>(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2); // zz: the depth k_raster stored (same operations)
 }
 // scalar-tail ("S") semantics (src/Rasterizer.cpp:470-492)
-template <class M>
+template <class M, int SH = -1, bool L2P150 = false>
 __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
@@ -702,7 +750,7 @@ __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const Shade
   normalize3(m, nx, ny, nz);
   float u = alpha * a.u0 + beta * a.u1 + gamma * a.u2;
   float v = alpha * a.v0 + beta * a.v1 + gamma * a.v2;
-  s_shade(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2);
+  s_shade<M, SH, L2P150>(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2);
 }
 
 #ifdef SRZ_ISA_PROBE
@@ -722,11 +770,11 @@ __global__ void probe_v(RenderArgs a, float *o) {
   float r0, r1, r2;
 #ifdef SRZ_PROBE_S
   FastMath fm;
-  shade_pixel_s(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
+  shade_pixel_s<FastMath>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #else
   FastMath fm;
-  shade_pixel_v(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
+  shade_pixel_v<FastMath>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #endif
   o[threadIdx.x] = r0 + r1 + r2;
@@ -734,252 +782,282 @@ __global__ void probe_v(RenderArgs a, float *o) {
 #endif
 
 // ================================================================================================================
-// k_raster — VISIBILITY: one wave per 32x32 tile
+// k_raster — VISIBILITY: one wave per 32x32 tile, ORDER-INDEPENDENT
+//
+// The reference walks the triangles in submission order; a fragment of the 8-wide ("V") columns replaces the pixel iff
+// z < zbuf, one of the scalar-tail ("S") columns iff !(z > zbuf) (src/Rasterizer.cpp:334,475).  For ordinary depths
+// (not NaN, not ±0) the pixel's final state is a function of the SET of its fragments:
+//     final z = the smallest z;   final owner = the LAST S fragment at that z if there is one (every later S passes <=,
+//     no later V passes <), otherwise the FIRST V fragment at that z (later ones fail <); an incoming depth equal to the
+//     smallest z keeps the pixel against V fragments and loses it to S fragments.
+// So every pixel holds ONE 64-bit key  (order-preserving image of z) << 32 | tie-break  and every fragment is an LDS
+// ds_min_u64, in any order:   tie-break = 0x7ffffffe - idx (S)  <  0x7fffffff (incoming depth)  <  0x80000000 | idx (V),
+// idx = the triangle's index in the frame = its submission order.
+// What the min cannot express is detected and handed to k_raster_slow (the reference's ordered algorithm): a NaN depth
+// that passes an S test (S fragments with NaN z and NaN incoming depths get the smallest key, 0) and a final depth of
+// ±0 (-0 and +0 compare equal as floats but not as keys); both leave their mark in the pixel's final key.
+//
+// Because order is irrelevant the tile's (triangle, pixel) candidates can be spread DENSELY over the lanes instead of
+// giving every triangle a wave pass of its own.  Per chunk of 64 list records (one per lane, geometry of bbox ∩ tile
+// computed in parallel) the work is flattened into ITEMS — a V item is an 8-pixel piece of one bbox row, an S item is one
+// pixel of the <= 7 scalar-tail columns — numbered by an exclusive scan of the per-triangle item counts.  A batch of 64
+// consecutive items is then one item per lane: the triangles whose first item falls into the batch mark that position in
+// LDS, an inclusive max-scan over the marks tells every lane its triangle, whose record comes over the LDS crossbar
+// (ds_bpermute), and the lane tests its 8 pixels (V) or its pixel (S) with the reference's arithmetic.
 // ================================================================================================================
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 // streaming 16-byte store: written once, never re-read by this pipeline
 __device__ __forceinline__ void store_nt(float *p, const float4 &v) {
   f32x4 w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, reinterpret_cast<f32x4 *>(p));
 }
+// order-preserving image of binary32 in u32 (-0 just below +0, negative NaNs below -inf, positive NaNs above +inf)
+__device__ __forceinline__ uint32_t zkey_of(float z) {
+  const uint32_t b = f2u(z);
+  return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float z_of_key(uint32_t k) {
+  return u2f(k ^ (~(uint32_t)((int32_t)k >> 31) | 0x80000000u));
+}
+constexpr uint32_t TB_NONE = 0x7fffffffu; // tie-break of the incoming depth
+__device__ __forceinline__ float bperm_f(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ uint32_t bperm_u(int addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v); }
 
-template <bool STATS>
-__global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_z[RASTER_WAVES][TILE * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_id[RASTER_WAVES][TILE * LDS_STRIDE];
+__global__ __launch_bounds__(64) void k_raster(RenderArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned long long s_key[TILE * KEY_STRIDE];
 
   const int lane = threadIdx.x & 63;
   // XCD-aware tile assignment.  Workgroups are dealt round-robin to the 8 XCDs in launch order, and launch order is
   // strict: one XCD whose slots are full of long tiles stalls the dispatch of everything behind it.  So workgroup i
   // renders frame (i % 8) of its group of 8 frames: the 8 XCDs walk the SAME tile sequence in lockstep (balanced by
-  // construction), and all tiles of one frame — hence its band lists — live in ONE XCD's L2.
+  // construction), and all tiles of one frame — hence its tile lists — live in ONE XCD's L2.
   const uint32_t wg = blockIdx.x;
   const uint32_t xcd = wg & 7u, j = wg >> 3;
   const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
   const uint32_t frame = (j / tiles_per_frame) * 8u + xcd, tile = j % tiles_per_frame;
   if (frame >= a.n_frames) return;
+  // nothing listed for this tile: nothing to rasterise, and its clear (if any) is k_clear's job
+  const uint32_t cnt = as_const(a.tile_cnt)[(size_t)frame * tiles_per_frame + tile];
+  if (cnt == 0u) return;
+  const uint32_t off = as_const(a.tile_off)[(size_t)frame * tiles_per_frame + tile];
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
+  const uint32_t flags = fd->flags | a.flags_or;
+  if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
+    if (lane == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
+    return;
+  }
   const uint32_t lb = tile / a.tiles_x;
   const int W = fd->width, H = fd->height;
-  const uint32_t n_tris = fd->n_tris;
-  const uint32_t flags = fd->flags | a.flags_or;
-  const int wave = 0;
   const int tx0 = (int)(tile % a.tiles_x) * TILE;
-  if (tx0 >= W) return; // whole wave leaves; no workgroup barrier is used in this kernel
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int ty0 = band * BAND;
   const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
   const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
-  {  // no bbox of the band list reaches this tile: nothing to rasterise, and its clear (if any) is k_clear's job
-    const uint32_t txi = (uint32_t)tx0 / TILE;
-    const uint32_t word = as_const(a.tile_mask)[((size_t)frame * a.n_local_bands + lb) * a.mask_words + (txi >> 5)];
-    if (!((word >> (txi & 31u)) & 1u)) return;
-  }
-  float *zl = s_z[wave];
-  uint32_t *il = s_id[wave];
-
   const size_t row0 = (size_t)lb * BAND;
   float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
   uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
 
-  const unsigned long long tA = STATS ? __builtin_readcyclecounter() : 0;
-  const unsigned long long wallA = a.timeline ? wall_clock64() : 0;
-  uint32_t n_hit_tris = 0;
-  // ---- phase A: tile init (fused clear → +inf, else load the in/out z plane) ---------------------------------
+  // ---- phase A: tile init (fused clear → +inf, else the in/out z plane) with the incoming-depth tie-break ----------
   for (int i = lane; i < TILE * TILE; i += 64) {
-    int ly = i >> 5, lx = i & 31;
+    const int ly = i >> 5, lx = i & 31;
     float z = __builtin_inff();
     if (!fused && tx0 + lx <= tx1 && ty0 + ly <= ty1) z = out0[(size_t)ly * W + tx0 + lx];
-    zl[ly * LDS_STRIDE + lx] = z;
-    il[ly * LDS_STRIDE + lx] = NO_TRI;
+    const uint32_t zk = (z == z) ? zkey_of(z) : 0u; // a NaN already in the buffer: only the ordered algorithm knows
+    s_key[ly * KEY_STRIDE + lx] = ((unsigned long long)zk << 32) | TB_NONE;
   }
+  // the pad key of every row is scratch: 64 dword marks, mark r in row r / 2
+  // (plain LDS accesses: the mark a triangle writes may be the one this lane reads, so the compiler keeps their order;
+  // `volatile` would turn them into flat, system-scope accesses)
+  uint32_t *const s_mark = reinterpret_cast<uint32_t *>(s_key);
+  auto mark_at = [](uint32_t r) { return ((r >> 1) * (uint32_t)KEY_STRIDE + TILE) * 2u + (r & 1u); };
+  const uint32_t my_mark = mark_at((uint32_t)lane);
+  s_mark[my_mark] = 0u;
   __builtin_amdgcn_wave_barrier();
 
-  const unsigned long long tB = STATS ? __builtin_readcyclecounter() : 0;
-  unsigned long long n_blocks = 0;
-  // ---- phase B: walk the band's triangle list in submission order ---------------------------------------------
-  // (the list length does not depend on the frame descriptor — count_off = frame * n_local_bands by construction — so
-  // its load is in flight together with the descriptor's, and the first chunk of records is fetched SPECULATIVELY for all
-  // 64 lanes before the length is known: two dependent round trips per tile instead of three.  The list region is padded,
-  // lanes beyond the length are masked.)
-  const uint32_t cnt = (flags & 0x100u) ? 0u : as_const(a.band_count)[frame * a.n_local_bands + lb];
-  const SRZ_CAS f32x4 *recs =
-      reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.band_recs) + fd->list_off + (uint64_t)lb * n_tris);
-  unsigned long long n_frag = 0, n_shaded = 0;
-
-  // software pipeline: the next chunk's records are in flight while the current chunk is rasterised
-  f32x4 n0 = recs[3 * lane], n1 = recs[3 * lane + 1], n2 = recs[3 * lane + 2];
+  // ---- phase B: the tile's list, 64 records at a time --------------------------------------------------------------
+  const SRZ_CAS f32x4 *recs = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.pool) + off);
+  f32x4 n0, n1, n2, n3;
   bool nv = (uint32_t)lane < cnt;
+  {
+    const uint32_t e = nv ? (uint32_t)lane : 0u;
+    n0 = recs[4 * e], n1 = recs[4 * e + 1], n2 = recs[4 * e + 2], n3 = recs[4 * e + 3];
+  }
   for (uint32_t base = 0; base < cnt; base += 64) {
-    const f32x4 r0 = n0, r1 = n1, r2 = n2;
+    const f32x4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
     const bool valid = nv;
-    nv = false;
-    if (base + 64 + lane < cnt) {
-      const uint32_t e = base + 64 + lane;
-      n0 = recs[3 * e], n1 = recs[3 * e + 1], n2 = recs[3 * e + 2];
-      nv = true;
+    nv = base + 64 + lane < cnt;
+    if (base + 64 < cnt) { // the next chunk is in flight while this one is rasterised
+      const uint32_t e = nv ? base + 64 + lane : base;
+      n0 = recs[4 * e], n1 = recs[4 * e + 1], n2 = recs[4 * e + 2], n3 = recs[4 * e + 3];
     }
-    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx
-    // (by-value helper: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
-    const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z), my = f2u(r2.w);
+    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx | r3 = v_inv s_area
+    const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z), my_idx = f2u(r2.w);
     const int bsx = (int16_t)(bbx & 0xffff), bsy = (int16_t)(bbx >> 16), bex = (int16_t)(bby & 0xffff), bey = (int16_t)(bby >> 16);
-    const bool hit = valid && bex >= tx0 && bsx <= tx1;
-    TriXY t;
-    t.ax = r0.x, t.ay = r0.y, t.z0 = r0.z, t.bx = r0.w, t.by = r1.x, t.z1 = r1.y, t.cx = r1.z, t.cy = r1.w, t.z2 = r2.x;
-    t.v_inv = t.s_area = 0.0f;
-    // Per-lane (= per-triangle) geometry of bbox ∩ tile in TILE-LOCAL coordinates, computed for the whole chunk in
-    // parallel and packed into one word so that the serial per-triangle loop only unpacks it:
-    //   [4:0] x0  [9:5] x1  [14:10] y0  [19:15] y1  [25:20] v = first scalar-tail column (V part = [x0,v-1], S = [v,x1])
-    //   [27:26] log2(block width) of the V sweep  [29:28] of the S sweep   (block = BW x 64/BW pixels: 8x8, 16x4, 4x16,
-    //   whichever needs the fewest blocks)
-    uint32_t geom = 0;
-    if (hit) {
-      BranchMath bm;
-      tri_consts(bm, t);
-      const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
-      const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
-      const int v = min(max(vend - tx0, x0), x1 + 1);
-      const int h = y1 - y0 + 1, wv = v - x0, ws = x1 + 1 - v;
-      auto pick = [h](int w) {
-        const int n88 = ((w + 7) >> 3) * ((h + 7) >> 3), n164 = ((w + 15) >> 4) * ((h + 3) >> 2), n416 = ((w + 3) >> 2) * ((h + 15) >> 4);
-        int l = 3;
-        if (n164 < n88 && n164 <= n416) l = 4;
-        if (n416 < n88 && n416 < n164) l = 2;
-        return l;
-      };
-      geom = (uint32_t)x0 | ((uint32_t)x1 << 5) | ((uint32_t)y0 << 10) | ((uint32_t)y1 << 15) | ((uint32_t)v << 20) |
-             ((uint32_t)(pick(wv) - 2) << 26) | ((uint32_t)(pick(ws) - 2) << 28);
-    }
-    unsigned long long m = __ballot(hit);
-    n_hit_tris += (uint32_t)__popcll(m);
-    while (m) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      // broadcast triangle j to the wave (uniform values → SGPRs)
-      TriXY u;
-      u.ax = rl_f(t.ax, j), u.ay = rl_f(t.ay, j), u.bx = rl_f(t.bx, j), u.by = rl_f(t.by, j), u.cx = rl_f(t.cx, j);
-      u.cy = rl_f(t.cy, j), u.z0 = rl_f(t.z0, j), u.z1 = rl_f(t.z1, j), u.z2 = rl_f(t.z2, j);
-      u.v_inv = rl_f(t.v_inv, j), u.s_area = rl_f(t.s_area, j);
-      const uint32_t idx = (uint32_t)rl_i((int)my, j);
-      const uint32_t g = (uint32_t)rl_i((int)geom, j);
-      const int x0 = g & 31, x1 = (g >> 5) & 31, y0 = (g >> 10) & 31, y1 = (g >> 15) & 31, vx = (g >> 20) & 63;
-      if (y1 < y0) continue; // (cannot happen for a band hit; keeps the loops well-formed)
-      if (vx > x0) { // ---- "V" sweep over columns [x0, vx-1] -------------------------------------------------
-        const int lbw = (int)((g >> 26) & 3) + 2, bw = 1 << lbw, bh = 64 >> lbw;
-        const int lx = lane & (bw - 1), ly = lane >> lbw;
-        for (int yb = y0; yb <= y1; yb += bh) {
-          const int yl = yb + ly;
-          const float fy = (float)(ty0 + yl);
-          const float PBy = u.by - fy, PCy = u.cy - fy, PAy = u.ay - fy;
-          const bool rowok = yl <= y1;
-          for (int xb = x0; xb < vx; xb += bw) {
-            const int xl = xb + lx;
-            const float fx = (float)(tx0 + xl);
-            const float PBx = u.bx - fx, PCx = u.cx - fx, PAx = u.ax - fx;
-            const float aPBC = fmsubf(PBx, PCy, PCx * PBy), aPCA = fmsubf(PCx, PAy, PAx * PCy);
-            const float al = aPBC * u.v_inv, be = aPCA * u.v_inv, ga = 1.0f - (al + be);
-            const float z = fmaf_(al, u.z0, fmaf_(be, u.z1, ga * u.z2));
-            const int li = min(yl * LDS_STRIDE + xl, TILE * LDS_STRIDE - 1); // clamped: idle lanes read a valid word
-            const float zold = zl[li];
-            // 0<al<1 & 0<be<1 & 0<ga<1  <=>  al>0 & be>0 & ga>0 & ga<1 (al+be is rounded monotonically, so ga>0
-            // forces al,be <= al+be < 1); every compare is ordered, so NaNs reject exactly like _CMP_*_OQ
-            const bool inside = rowok & (xl < vx) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
-            const bool pass = inside & (z < zold); // strict (src/Rasterizer.cpp:334)
-            if (pass) {
-              zl[li] = z;
-              il[li] = idx;
-            }
-            if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
-          }
-        }
-      }
-      if (vx <= x1) { // ---- scalar-tail "S" sweep over columns [vx, x1] (<= 7 wide) -----------------------------
-        const int lbw = (int)((g >> 28) & 3) + 2, bw = 1 << lbw, bh = 64 >> lbw;
-        const int lx = lane & (bw - 1), ly = lane >> lbw;
-        const float ABx = u.bx - u.ax, ABy = u.by - u.ay, BCx = u.cx - u.bx, BCy = u.cy - u.by, CAx = u.ax - u.cx,
-                    CAy = u.ay - u.cy;
-        for (int yb = y0; yb <= y1; yb += bh) {
-          const int yl = yb + ly;
-          const float fy = (float)(ty0 + yl);
-          const bool rowok = yl <= y1;
-          for (int xb = vx; xb <= x1; xb += bw) {
-            const int xl = xb + lx;
-            const float fx = (float)(tx0 + xl);
-            // insideTriangle (src/Rasterizer.cpp:11-41)
-            const float APx = fx - u.ax, APy = fy - u.ay, BPx = fx - u.bx, BPy = fy - u.by, CPx = fx - u.cx, CPy = fy - u.cy;
-            const float e0 = ABx * APy - ABy * APx, e1 = BCx * BPy - BCy * BPx, e2 = CAx * CPy - CAy * CPx;
-            const bool in_tri = ((e0 > 0) & (e1 > 0) & (e2 > 0)) | ((e0 < 0) & (e1 < 0) & (e2 < 0));
-            // barycentric (scalar) + z (src/Rasterizer.cpp:43-70,473)
-            const float PAx = u.ax - fx, PAy = u.ay - fy, PBx = u.bx - fx, PBy = u.by - fy, PCx = u.cx - fx, PCy = u.cy - fy;
-            const float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
-            const float al = aPBC / u.s_area, be = aPCA / u.s_area, ga = 1.0f - al - be;
-            const float z = al * u.z0 + be * u.z1 + ga * u.z2;
-            const int li = min(yl * LDS_STRIDE + xl, TILE * LDS_STRIDE - 1);
-            const float zold = zl[li];
-            const bool inside = rowok & (xl <= x1) & in_tri;
-            const bool pass = inside & !(z > zold); // <= passes, NaN passes (src/Rasterizer.cpp:475)
-            if (pass) {
-              zl[li] = z;
-              il[li] = idx | S_CLASS_BIT;
-            }
-            if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0, n_blocks += (lane == 0);
-          }
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  // does any pixel of the tile have an owner?  (only tiles that were hit at all need the 16-words-per-lane scan)
-  bool any_owner = false;
-  if (n_hit_tris) {
-    for (int it = 0; it < 4; ++it) {
-      const uint4 q = *reinterpret_cast<const uint4 *>(&il[(it * 8 + (lane >> 3)) * LDS_STRIDE + (lane & 7) * 4]);
-      any_owner |= (q.x & q.y & q.z & q.w) != NO_TRI;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  const bool tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
+    // geometry of bbox ∩ tile in TILE-LOCAL coordinates: V columns [x0, v-1] in nseg pieces of 8, S columns [v, x1]
+    const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
+    const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
+    const int v = min(max(vend - tx0, x0), x1 + 1);
+    const bool ok = valid && x0 <= x1 && y0 <= y1;
+    const uint32_t h = ok ? (uint32_t)(y1 - y0 + 1) : 0u, nseg = (uint32_t)(v - x0 + 7) >> 3, ws = (uint32_t)(x1 + 1 - v);
+    const uint32_t nV = __umul24(h, nseg), nS = __umul24(h, ws); // <= 128 / <= 224 per triangle
+    const uint32_t geom = (uint32_t)x0 | ((uint32_t)y0 << 5) | ((uint32_t)v << 10) | (nseg << 16) | (ws << 19);
+    const uint32_t packed = nV | (nS << 16), incl = wave_scan_add(packed);
+    const uint32_t offs = incl - packed; // exclusive: first V item | first S item << 16
+    const uint32_t tot = (uint32_t)rl_i((int)incl, 63), TV = tot & 0xffffu, TS = tot >> 16;
 
-  const unsigned long long tC = STATS ? __builtin_readcyclecounter() : 0;
-  // ---- phase C: write-out ---------------------------------------------------------------------------------------
+    // ---- V items: 8 pixels of one row each (barycentric(__m256) + inside mask + z, src/Rasterizer.cpp:89-127,310-334)
+    uint32_t carry = 0;
+    for (uint32_t P0 = 0; P0 < TV; P0 += 64) {
+      const uint32_t r = (offs & 0xffffu) - P0;
+      if (nV != 0u && r < 64u) s_mark[mark_at(r)] = (uint32_t)lane + 1u;
+      __builtin_amdgcn_wave_barrier();
+      uint32_t m = s_mark[my_mark];
+      __builtin_amdgcn_wave_barrier();
+      s_mark[my_mark] = 0u;
+      m = max(wave_scan_max(m), carry);
+      carry = (uint32_t)rl_i((int)m, 63);
+      const int src = (int)((m - 1u) & 63u) * 4;
+      const float ax = bperm_f(src, r0.x), ay = bperm_f(src, r0.y), z0 = bperm_f(src, r0.z), bx = bperm_f(src, r0.w);
+      const float by = bperm_f(src, r1.x), z1 = bperm_f(src, r1.y), cx = bperm_f(src, r1.z), cy = bperm_f(src, r1.w);
+      const float z2 = bperm_f(src, r2.x), v_inv = bperm_f(src, r3.x);
+      const uint32_t g = bperm_u(src, geom), idx = bperm_u(src, my_idx), o = bperm_u(src, offs);
+      const uint32_t item = P0 + (uint32_t)lane, i = item - (o & 0xffffu), ns = (g >> 16) & 7u;
+      // row = i / ns: (i + 0.5) / ns is at least 1 / 8 away from every integer, far more than the error of v_rcp
+      const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)ns)), seg = i - __umul24(row, ns);
+      const uint32_t yl = ((g >> 5) & 31u) + row, xs = (g & 31u) + 8u * seg;
+      const int lim = item < TV ? (int)((g >> 10) & 63u) - (int)xs : 0; // pixels of this piece inside the V columns
+      const float fy = (float)(ty0 + (int)yl), fx0 = (float)(tx0 + (int)xs);
+      const float PBy = by - fy, PCy = cy - fy, PAy = ay - fy;
+      unsigned long long *kp = s_key + ((yl << 5) + yl) + xs; // yl * KEY_STRIDE
+      const uint32_t tb = 0x80000000u | idx;
+      // all the arithmetic of the 8 independent pixels first, then the predicated LDS atomics
+      uint32_t zk[8];
+      bool inside[8];
+#pragma unroll
+      for (int px = 0; px < 8; ++px) {
+        const float fx = fx0 + (float)px; // (exact)
+        const float PBx = bx - fx, PCx = cx - fx, PAx = ax - fx;
+        const float aPBC = fmsubf(PBx, PCy, PCx * PBy), aPCA = fmsubf(PCx, PAy, PAx * PCy);
+        const float al = aPBC * v_inv, be = aPCA * v_inv, ga = 1.0f - (al + be);
+        const float z = fmaf_(al, z0, fmaf_(be, z1, ga * z2));
+        // 0<al<1 & 0<be<1 & 0<ga<1  <=>  al>0 & be>0 & ga>0 & ga<1 (al+be is rounded monotonically, so ga>0 forces
+        // al,be <= al+be < 1); every compare is ordered, so NaNs reject exactly like _CMP_*_OQ
+        inside[px] = (px < lim) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
+        // a NaN depth never passes '<': min(z, +inf) turns it into a depth that loses to everything, the incoming one included
+        zk[px] = zkey_of(__builtin_fminf(z, __builtin_inff()));
+        asm volatile("" : "+v"(zk[px])); // (keeps the depth arithmetic out of the predicated blocks: 8 pixels of straight-line code)
+      }
+#pragma unroll
+      for (int px = 0; px < 8; ++px)
+        if (inside[px])
+          __hip_atomic_fetch_min(kp + px, ((unsigned long long)zk[px] << 32) | tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // ---- S items: one pixel each (insideTriangle + barycentric(scalar) + z, src/Rasterizer.cpp:11-70,465-477) --------
+    carry = 0;
+    for (uint32_t P0 = 0; P0 < TS; P0 += 64) {
+      const uint32_t r = (offs >> 16) - P0;
+      if (nS != 0u && r < 64u) s_mark[mark_at(r)] = (uint32_t)lane + 1u;
+      __builtin_amdgcn_wave_barrier();
+      uint32_t m = s_mark[my_mark];
+      __builtin_amdgcn_wave_barrier();
+      s_mark[my_mark] = 0u;
+      m = max(wave_scan_max(m), carry);
+      carry = (uint32_t)rl_i((int)m, 63);
+      const int src = (int)((m - 1u) & 63u) * 4;
+      const float ax = bperm_f(src, r0.x), ay = bperm_f(src, r0.y), z0 = bperm_f(src, r0.z), bx = bperm_f(src, r0.w);
+      const float by = bperm_f(src, r1.x), z1 = bperm_f(src, r1.y), cx = bperm_f(src, r1.z), cy = bperm_f(src, r1.w);
+      const float z2 = bperm_f(src, r2.x), s_area = bperm_f(src, r3.y);
+      const uint32_t g = bperm_u(src, geom), idx = bperm_u(src, my_idx), o = bperm_u(src, offs);
+      const uint32_t item = P0 + (uint32_t)lane, i = item - (o >> 16), w = (g >> 19) & 7u;
+      const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w)), col = i - __umul24(row, w);
+      const uint32_t yl = ((g >> 5) & 31u) + row, xl = ((g >> 10) & 63u) + col;
+      const float fy = (float)(ty0 + (int)yl), fx = (float)(tx0 + (int)xl);
+      const float ABx = bx - ax, ABy = by - ay, BCx = cx - bx, BCy = cy - by, CAx = ax - cx, CAy = ay - cy;
+      const float APx = fx - ax, APy = fy - ay, BPx = fx - bx, BPy = fy - by, CPx = fx - cx, CPy = fy - cy;
+      const float e0 = ABx * APy - ABy * APx, e1 = BCx * BPy - BCy * BPx, e2 = CAx * CPy - CAy * CPx;
+      const bool in_tri = ((e0 > 0) & (e1 > 0) & (e2 > 0)) | ((e0 < 0) & (e1 < 0) & (e2 < 0));
+      const float PAx = ax - fx, PAy = ay - fy, PBx = bx - fx, PBy = by - fy, PCx = cx - fx, PCy = cy - fy;
+      const float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
+      const float al = aPBC / s_area, be = aPCA / s_area, ga = 1.0f - al - be;
+      const float z = al * z0 + be * z1 + ga * z2;
+      if ((item < TS) & in_tri) { // '<=' passes and so does a NaN depth (src/Rasterizer.cpp:475): key 0 = "ask the ordered rasteriser"
+        const uint32_t zk = (z == z) ? zkey_of(z) : 0u;
+        __hip_atomic_fetch_min(s_key + ((yl << 5) + yl) + xl, ((unsigned long long)zk << 32) | (0x7ffffffeu - idx), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase C: decode the keys, write out ------------------------------------------------------------------------
+  //  some final key needs the ordered algorithm  : the tile goes to k_raster_slow, nothing is written here
   //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
   //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
+  float4 z4[4];
+  uint4 id4[4];
+  bool any_owner = false, redo = false;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+    const unsigned long long *kr = &s_key[ly * KEY_STRIDE + lx4]; // (rows are 264 bytes apart: 8-byte aligned reads)
+    const unsigned long long k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
+    const uint32_t tb[4] = {(uint32_t)k0, (uint32_t)k1, (uint32_t)k2, (uint32_t)k3};
+    const uint32_t zk[4] = {(uint32_t)(k0 >> 32), (uint32_t)(k1 >> 32), (uint32_t)(k2 >> 32), (uint32_t)(k3 >> 32)};
+    float zz[4];
+    uint32_t id[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      redo |= (zk[k] == 0u) | ((zk[k] + 0x80000001u) <= 1u); // NaN that passed / final depth ±0
+      zz[k] = z_of_key(zk[k]);
+      id[k] = (tb[k] & 0x80000000u) ? (tb[k] & 0x7fffffffu) : (tb[k] == TB_NONE ? NO_TRI : ((0x7ffffffeu - tb[k]) | S_CLASS_BIT));
+      any_owner |= tb[k] != TB_NONE;
+    }
+    z4[it] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+    id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
+  }
+  if (__ballot(redo) != 0ull) {
+    if (lane == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
+    return;
+  }
+  const bool tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
   const bool vec_ok = (W & 3) == 0;
-  if ((tile_has_owner || fused) && !(flags & 0x400u)) {
+  if (tile_has_owner || fused) {
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
       const int y = ty0 + ly, x4 = tx0 + lx4;
       if (y > ty1 || x4 > tx1) continue;
-      const float4 z4 = *reinterpret_cast<const float4 *>(&zl[ly * LDS_STRIDE + lx4]);
       float *gz = out0 + (size_t)ly * W + x4;
       const bool full = vec_ok && x4 + 3 <= tx1;
       if (tile_has_owner) {
-        const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
         uint32_t *gv = vis0 + (size_t)ly * W + x4;
         if (full) {
-          store_nt(gz, z4);                      // final: k_shade recomputes the depth it needs from the owner triangle
-          *reinterpret_cast<uint4 *>(gv) = id4; // re-read by k_shade: keep it cacheable
+          store_nt(gz, z4[it]);                      // final: k_shade recomputes the depth it needs from the owner triangle
+          *reinterpret_cast<uint4 *>(gv) = id4[it]; // re-read by k_shade: keep it cacheable
         } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4.M, gv[K_] = id4.M;
+  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, gv[K_] = id4[it].M;
           SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
         }
       } else { // touched by a bbox but owned by nobody: the clear itself
         if (full) {
-          store_nt(gz, z4);
+          store_nt(gz, z4[it]);
           store_nt(gz + plane, zero4);
           store_nt(gz + 2 * plane, zero4);
           store_nt(gz + 3 * plane, zero4);
         } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4.M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
+  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
           SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
         }
@@ -988,27 +1066,217 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
   if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame], 1u)] = tile;
-  if (a.timeline && lane == 0) { // diagnostic: per-tile residency (srz_debug_timeline)
-    unsigned hw = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned long long *tl = a.timeline + 4ull * ((size_t)frame * tiles_per_frame + tile);
-    tl[0] = wallA, tl[1] = wall_clock64(), tl[2] = hw, tl[3] = n_hit_tris;
+}
+
+// ================================================================================================================
+// k_raster_slow — the reference's ORDERED algorithm for the tiles k_raster could not finish: tiles whose band did not
+// fit the record pool, tiles where a NaN or ±0 depth decides a pixel, and every touched tile of a counting run or under
+// SRZ_ORDERED_RASTER.  One wave per tile (persistent grid over the list); the wave walks the FRAME's triangles in
+// submission order (64 bboxes at a time, chunks whose rows miss the tile are skipped), broadcasts one hit triangle at a
+// time into SGPRs and sweeps bbox ∩ tile in 64-pixel blocks against z + owner planes in LDS: a wave's LDS operations are
+// ordered, so "last writer in submission order wins" needs no lock.
+// ================================================================================================================
+template <bool STATS>
+__global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
+  __shared__ __attribute__((aligned(16))) float zl[TILE * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t il[TILE * LDS_STRIDE];
+  const int lane = threadIdx.x & 63;
+  const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
+  const uint32_t n_slow = *as_const(a.slow_count);
+  unsigned long long n_frag = 0, n_shaded = 0;
+  for (uint32_t e = blockIdx.x; e < n_slow; e += gridDim.x) {
+    const uint32_t entry = as_const(a.slow_list)[e];
+    const uint32_t frame = entry / tiles_per_frame, tile = entry % tiles_per_frame;
+    const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
+    const uint32_t lb = tile / a.tiles_x;
+    const int W = fd->width, H = fd->height;
+    const uint32_t n_tris = fd->n_tris;
+    const uint32_t flags = fd->flags | a.flags_or;
+    const int tx0 = (int)(tile % a.tiles_x) * TILE;
+    const int band = (int)lb * a.shard_world + a.shard_rank;
+    const int ty0 = band * BAND;
+    const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
+    const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
+    const size_t row0 = (size_t)lb * BAND;
+    float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W;
+    uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
+    // ---- phase A: tile init (fused clear → +inf, else load the in/out z plane) -------------------------------
+    for (int i = lane; i < TILE * TILE; i += 64) {
+      const int ly = i >> 5, lx = i & 31;
+      float z = __builtin_inff();
+      if (!fused && tx0 + lx <= tx1 && ty0 + ly <= ty1) z = out0[(size_t)ly * W + tx0 + lx];
+      zl[ly * LDS_STRIDE + lx] = z;
+      il[ly * LDS_STRIDE + lx] = NO_TRI;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase B: the frame's triangles in submission order ------------------------------------------------------
+    const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
+    const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
+    const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->chunk_off;
+    const uint32_t n_chunks = (n_tris + 63) / 64;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const uint32_t cr = chunk_rows[c]; // wave-uniform
+      if ((int)(int16_t)(cr & 0xffffu) > ty1 || (int)(int16_t)(cr >> 16) < ty0) continue;
+      const uint32_t my = c * 64u + (uint32_t)lane;
+      const u32x2 bb = bbox[min(my, n_tris - 1u)];
+      const int bsx = (int16_t)(bb.x & 0xffff), bsy = (int16_t)(bb.x >> 16), bex = (int16_t)(bb.y & 0xffff), bey = (int16_t)(bb.y >> 16);
+      const bool hit = my < n_tris && bsx <= bex && bex >= tx0 && bsx <= tx1 && bey >= ty0 && bsy <= ty1;
+      unsigned long long m = __ballot(hit);
+      if (m == 0ull) continue;
+      TriXY t;
+      t.ax = t.ay = t.bx = t.by = t.cx = t.cy = t.z0 = t.z1 = t.z2 = t.v_inv = t.s_area = 0.0f;
+      // Per-lane (= per-triangle) geometry of bbox ∩ tile in TILE-LOCAL coordinates, packed into one word:
+      //   [4:0] x0  [9:5] x1  [14:10] y0  [19:15] y1  [25:20] v = first scalar-tail column (V part = [x0,v-1], S = [v,x1])
+      //   [27:26] log2(block width) of the V sweep  [29:28] of the S sweep   (block = BW x 64/BW pixels: 8x8, 16x4, 4x16,
+      //   whichever needs the fewest blocks)
+      uint32_t geom = 0;
+      if (hit) {
+        const SRZ_CAS float *p = &tris[my].pos[0][0];
+        t.ax = p[0], t.ay = p[1], t.z0 = p[2], t.bx = p[3], t.by = p[4], t.z1 = p[5], t.cx = p[6], t.cy = p[7], t.z2 = p[8];
+        BranchMath bm;
+        tri_consts(bm, t);
+        const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
+        const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
+        const int v = min(max(vend - tx0, x0), x1 + 1);
+        const int h = y1 - y0 + 1, wv = v - x0, ws = x1 + 1 - v;
+        auto pick = [h](int w) {
+          const int n88 = ((w + 7) >> 3) * ((h + 7) >> 3), n164 = ((w + 15) >> 4) * ((h + 3) >> 2), n416 = ((w + 3) >> 2) * ((h + 15) >> 4);
+          int l = 3;
+          if (n164 < n88 && n164 <= n416) l = 4;
+          if (n416 < n88 && n416 < n164) l = 2;
+          return l;
+        };
+        geom = (uint32_t)x0 | ((uint32_t)x1 << 5) | ((uint32_t)y0 << 10) | ((uint32_t)y1 << 15) | ((uint32_t)v << 20) |
+               ((uint32_t)(pick(wv) - 2) << 26) | ((uint32_t)(pick(ws) - 2) << 28);
+      }
+      while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        // broadcast triangle j to the wave (uniform values → SGPRs)
+        TriXY u;
+        u.ax = rl_f(t.ax, j), u.ay = rl_f(t.ay, j), u.bx = rl_f(t.bx, j), u.by = rl_f(t.by, j), u.cx = rl_f(t.cx, j);
+        u.cy = rl_f(t.cy, j), u.z0 = rl_f(t.z0, j), u.z1 = rl_f(t.z1, j), u.z2 = rl_f(t.z2, j);
+        u.v_inv = rl_f(t.v_inv, j), u.s_area = rl_f(t.s_area, j);
+        const uint32_t idx = c * 64u + (uint32_t)j;
+        const uint32_t g = (uint32_t)rl_i((int)geom, j);
+        const int x0 = g & 31, x1 = (g >> 5) & 31, y0 = (g >> 10) & 31, y1 = (g >> 15) & 31, vx = (g >> 20) & 63;
+        if (y1 < y0) continue; // (cannot happen for a hit; keeps the loops well-formed)
+        if (vx > x0) { // ---- "V" sweep over columns [x0, vx-1] -------------------------------------------------
+          const int lbw = (int)((g >> 26) & 3) + 2, bw = 1 << lbw, bh = 64 >> lbw;
+          const int lx = lane & (bw - 1), ly = lane >> lbw;
+          for (int yb = y0; yb <= y1; yb += bh) {
+            const int yl = yb + ly;
+            const float fy = (float)(ty0 + yl);
+            const float PBy = u.by - fy, PCy = u.cy - fy, PAy = u.ay - fy;
+            const bool rowok = yl <= y1;
+            for (int xb = x0; xb < vx; xb += bw) {
+              const int xl = xb + lx;
+              const float fx = (float)(tx0 + xl);
+              const float PBx = u.bx - fx, PCx = u.cx - fx, PAx = u.ax - fx;
+              const float aPBC = fmsubf(PBx, PCy, PCx * PBy), aPCA = fmsubf(PCx, PAy, PAx * PCy);
+              const float al = aPBC * u.v_inv, be = aPCA * u.v_inv, ga = 1.0f - (al + be);
+              const float z = fmaf_(al, u.z0, fmaf_(be, u.z1, ga * u.z2));
+              const int li = min(yl * LDS_STRIDE + xl, TILE * LDS_STRIDE - 1); // clamped: idle lanes read a valid word
+              const float zold = zl[li];
+              const bool inside = rowok & (xl < vx) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
+              const bool pass = inside & (z < zold); // strict (src/Rasterizer.cpp:334)
+              if (pass) {
+                zl[li] = z;
+                il[li] = idx;
+              }
+              if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0;
+            }
+          }
+        }
+        if (vx <= x1) { // ---- scalar-tail "S" sweep over columns [vx, x1] (<= 7 wide) -----------------------------
+          const int lbw = (int)((g >> 28) & 3) + 2, bw = 1 << lbw, bh = 64 >> lbw;
+          const int lx = lane & (bw - 1), ly = lane >> lbw;
+          const float ABx = u.bx - u.ax, ABy = u.by - u.ay, BCx = u.cx - u.bx, BCy = u.cy - u.by, CAx = u.ax - u.cx,
+                      CAy = u.ay - u.cy;
+          for (int yb = y0; yb <= y1; yb += bh) {
+            const int yl = yb + ly;
+            const float fy = (float)(ty0 + yl);
+            const bool rowok = yl <= y1;
+            for (int xb = vx; xb <= x1; xb += bw) {
+              const int xl = xb + lx;
+              const float fx = (float)(tx0 + xl);
+              // insideTriangle (src/Rasterizer.cpp:11-41)
+              const float APx = fx - u.ax, APy = fy - u.ay, BPx = fx - u.bx, BPy = fy - u.by, CPx = fx - u.cx, CPy = fy - u.cy;
+              const float e0 = ABx * APy - ABy * APx, e1 = BCx * BPy - BCy * BPx, e2 = CAx * CPy - CAy * CPx;
+              const bool in_tri = ((e0 > 0) & (e1 > 0) & (e2 > 0)) | ((e0 < 0) & (e1 < 0) & (e2 < 0));
+              // barycentric (scalar) + z (src/Rasterizer.cpp:43-70,473)
+              const float PAx = u.ax - fx, PAy = u.ay - fy, PBx = u.bx - fx, PBy = u.by - fy, PCx = u.cx - fx, PCy = u.cy - fy;
+              const float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
+              const float al = aPBC / u.s_area, be = aPCA / u.s_area, ga = 1.0f - al - be;
+              const float z = al * u.z0 + be * u.z1 + ga * u.z2;
+              const int li = min(yl * LDS_STRIDE + xl, TILE * LDS_STRIDE - 1);
+              const float zold = zl[li];
+              const bool inside = rowok & (xl <= x1) & in_tri;
+              const bool pass = inside & !(z > zold); // <= passes, NaN passes (src/Rasterizer.cpp:475)
+              if (pass) {
+                zl[li] = z;
+                il[li] = idx | S_CLASS_BIT;
+              }
+              if (STATS) n_frag += inside ? 1 : 0, n_shaded += pass ? 1 : 0;
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool any_owner = false;
+    for (int it = 0; it < 4; ++it) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(&il[(it * 8 + (lane >> 3)) * LDS_STRIDE + (lane & 7) * 4]);
+      any_owner |= (q.x & q.y & q.z & q.w) != NO_TRI;
+    }
+    const bool tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
+    // ---- phase C: write-out (as k_raster) ---------------------------------------------------------------------------
+    const bool vec_ok = (W & 3) == 0;
+    if (tile_has_owner || fused) {
+      const size_t plane = (size_t)a.local_rows * (size_t)W;
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int it = 0; it < 4; ++it) {
+        const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+        const int y = ty0 + ly, x4 = tx0 + lx4;
+        if (y > ty1 || x4 > tx1) continue;
+        const float4 z4 = *reinterpret_cast<const float4 *>(&zl[ly * LDS_STRIDE + lx4]);
+        float *gz = out0 + (size_t)ly * W + x4;
+        const bool full = vec_ok && x4 + 3 <= tx1;
+        if (tile_has_owner) {
+          const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
+          uint32_t *gv = vis0 + (size_t)ly * W + x4;
+          if (full) {
+            store_nt(gz, z4);
+            *reinterpret_cast<uint4 *>(gv) = id4;
+          } else {
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[K_] = z4.M, gv[K_] = id4.M;
+            SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+#undef SRZ_ST
+          }
+        } else {
+          if (full) {
+            store_nt(gz, z4);
+            store_nt(gz + plane, zero4);
+            store_nt(gz + 2 * plane, zero4);
+            store_nt(gz + 3 * plane, zero4);
+          } else {
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[K_] = z4.M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
+            SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+#undef SRZ_ST
+          }
+        }
+      }
+    }
+    if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame], 1u)] = tile;
+    __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
   }
   if (STATS) {
-    const unsigned long long tD = __builtin_readcyclecounter();
-    for (int o = 32; o > 0; o >>= 1) {
-      n_frag += __shfl_down(n_frag, o);
-      n_shaded += __shfl_down(n_shaded, o);
-      n_blocks += __shfl_down(n_blocks, o);
-    }
+    for (int o = 32; o > 0; o >>= 1) n_frag += __shfl_down(n_frag, o), n_shaded += __shfl_down(n_shaded, o);
     if (lane == 0) {
       if (n_frag) atomicAdd(&a.stats[ST_FRAGMENTS], n_frag);
       if (n_shaded) atomicAdd(&a.stats[ST_SHADED], n_shaded);
-      atomicAdd(&a.stats[ST_DBG_CYC_A], tB - tA);
-      atomicAdd(&a.stats[ST_DBG_CYC_B], tC - tB);
-      atomicAdd(&a.stats[ST_DBG_CYC_C], tD - tC);
-      atomicMax(&a.stats[ST_DBG_MAX_WAVE], tD - tA);
-      atomicAdd(&a.stats[ST_DBG_BLOCKS], n_blocks);
     }
   }
 }
@@ -1019,7 +1287,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster(RenderArgs a) {
 // the back), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
 // colours go to LDS planes and leave as coalesced 16-byte stores.
 // ================================================================================================================
-// k_clear — the fused clear of every tile NO bbox reaches (k_bands' tile masks), i.e. most of the framebuffer.  It runs
+// k_clear — the fused clear of every tile NO bbox reaches (k_bin's tile counts), i.e. most of the framebuffer.  It runs
 // on a second stream NEXT TO k_raster, which skips those tiles: no LDS and < 32 VGPRs, so its waves fit beside the
 // rasteriser's on every CU and the bulk of the frame's HBM writes drains under the visibility arithmetic.
 // One work item = one band of one frame, written ROW-MAJOR: a wave-instruction covers 1 KiB of one framebuffer row
@@ -1038,10 +1306,9 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
     const int rows = min(BAND, H - band * BAND);
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W;
-    const SRZ_CAS uint32_t *mask = as_const(a.tile_mask) + (size_t)br * a.mask_words;
+    const SRZ_CAS uint32_t *cnt = as_const(a.tile_cnt) + (size_t)br * a.tiles_x;
     for (int x4 = (int)threadIdx.x * 4; x4 < W; x4 += 256 * 4) {
-      const uint32_t tx = (uint32_t)x4 / TILE;
-      if ((mask[tx >> 5] >> (tx & 31u)) & 1u) continue; // some bbox reaches this tile: k_raster's
+      if (cnt[(uint32_t)x4 / TILE] != 0u) continue; // some bbox reaches this tile: the rasteriser's
       if (((W & 3) == 0)) {
         for (int ly = 0; ly < rows; ++ly) {
           float *g = base + (size_t)ly * W + x4;
@@ -1062,7 +1329,14 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 #ifndef SRZ_SHADE_MINW
 #define SRZ_SHADE_MINW 4
 #endif
-template <bool STATS>
+// Two builds of the same kernel share the persistent walk over the frames' work lists:
+//   FAST     frames whose shading is fully described at compile time up to the shader type: 2 lights, p = 150, every
+//            batch NORMAL / TEXTURE / PHONG (FD_FAST_SHADE, decided on the host).  Per 64-pixel chunk ONE wave-uniform
+//            switch picks the variant compiled for the chunk's shader type (mixed chunks take one pass per type);
+//            optimistic FastMath only — a tile where an operand left the fast range is handed back through redo_list.
+//   generic  every other frame with per-pixel generality (any shader, any light count, any exponent), FastMath first and
+//            the IEEE expansions for a tile that needs them; then the tiles the FAST build handed back, IEEE at once.
+template <bool STATS, bool FAST>
 __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
@@ -1073,20 +1347,12 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long n_vis = 0, n_vis_tex = 0;
-  // The persistent grid walks VIRTUAL workgroups v = (group of 8 frames, lane j, frame within the group): v shades every
-  // S-th entry of its frame's work list from entry j.  Frame-in-group is the fastest index, so physical workgroup b
-  // (on XCD b % 8) shades frame f with f % 8 == b % 8 — the XCD that rasterised it, whose L2 holds its z / owner ids —
-  // and the ~1000 resident workgroups cover only a group or two of frames at a time (triangles + ids stay L2-resident;
-  // dealing v over ALL frames at once thrashes L2: +10 % kernel time; dropping the XCD affinity: +5..12 %).
-  const uint32_t F = a.n_frames, tpf = a.n_local_bands * a.tiles_x, S = a.shade_split;
-  const uint32_t gsz = F < 8u ? F : 8u; // (fewer than 8 frames: every XCD works on all of them)
-  const uint32_t n_virtual = ((F + gsz - 1u) / gsz) * gsz * S;
-  for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
-  const uint32_t r = v % (gsz * S), f = (v / (gsz * S)) * gsz + r % gsz, j = r / gsz;
-  if (f >= F) continue;
-  const uint32_t n_work = as_const(a.work_count)[f];
-  for (uint32_t w = j; w < n_work; w += S) {
-    const uint32_t e = as_const(a.worklist)[(size_t)f * tpf + w];
+  const uint32_t tpf = a.n_local_bands * a.tiles_x;
+
+  // ---- one owned tile: entry e of frame f's work list.  mode: 0 = FAST variants, 1 = generic (FastMath, then IEEE if
+  //      needed), 2 = IEEE at once -----------------------------------------------------------------------------------------
+  auto shade_tile = [&](const uint32_t f, const uint32_t e, auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
     const uint32_t tx = e % a.tiles_x, lb = e / a.tiles_x;
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
     const int W = fd->width, H = fd->height;
@@ -1138,7 +1404,6 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
       SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
 #undef SRZ_LD
     }
-    if (flags & 0x200u) id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
     const int p0 = ly * TILE + lx4;
     *reinterpret_cast<uint4 *>(&s_ids[p0]) = id4;
     *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
@@ -1179,8 +1444,6 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
 
     // ---- 2. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
-    //         First with the optimistic FastMath; a tile where any operand left the fast range (degenerate normals,
-    //         a light straight above a pixel, ...) is shaded again with the IEEE expansions.
     const uint32_t cV = (nV + 63) >> 6, cS = (nS + 63) >> 6;
     // (one loop per class: a single loop over both keeps the registers of the V and of the S shader alive together)
     auto class_pass = [&](auto policy, auto is_v, bool count) -> bool {
@@ -1195,22 +1458,41 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
         const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
         float r0 = 1.f, r1 = 2.f, r2 = 3.f;
         ShadeDesc sd;
-        sd.shader = 0;
-        if (!(flags & 0x800u)) {
-          TriFetch tf;
-          fetch_tri(tris, tri_batch, id, tf);
-          const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-          sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
-          const int px = tx0 + (int)(p & 31), py = ty0 + (int)(p >> 5);
-          M m;
-          if (flags & 0x1000u)
-            r0 = tf.q0.x + tf.q5.w + (float)tf.batch, r1 = tf.q3.y + tf.q2.x + tf.q1.x, r2 = tf.q4.z + (float)sd.tw;
-          else if (isV)
-            shade_pixel_v(m, K, sd, tf, px, py, r0, r1, r2);
+        TriFetch tf;
+        fetch_tri(tris, tri_batch, id, tf);
+        const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+        sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+        const int px = tx0 + (int)(p & 31), py = ty0 + (int)(p >> 5);
+        M m;
+        if constexpr (MODE == 0) {
+          // one wave-uniform switch per chunk instead of per-pixel generality; a chunk that mixes shader types takes one
+          // pass per type (the lanes of the other types wait)
+          auto run = [&](auto sh) {
+            if constexpr (isV)
+              shade_pixel_v<M, decltype(sh)::value, true>(m, K, sd, tf, px, py, r0, r1, r2);
+            else
+              shade_pixel_s<M, decltype(sh)::value, true>(m, K, sd, tf, px, py, r0, r1, r2);
+          };
+          bool todo = true;
+          for (unsigned long long tm = __ballot(true); tm != 0ull; tm = __ballot(todo)) {
+            const int sh0 = __builtin_amdgcn_readlane(sd.shader, __builtin_ctzll(tm)); // type of the first pixel still to do
+            if (todo && sd.shader == sh0) {
+              if (sh0 == SRZ_SHADER_TEXTURE)
+                run(std::integral_constant<int, SRZ_SHADER_TEXTURE>{});
+              else if (sh0 == SRZ_SHADER_PHONG)
+                run(std::integral_constant<int, SRZ_SHADER_PHONG>{});
+              else
+                run(std::integral_constant<int, SRZ_SHADER_NORMAL>{});
+              todo = false;
+            }
+          }
+        } else {
+          if constexpr (isV)
+            shade_pixel_v<M>(m, K, sd, tf, px, py, r0, r1, r2);
           else
-            shade_pixel_s(m, K, sd, tf, px, py, r0, r1, r2);
-          if constexpr (std::is_same<M, FastMath>::value) bad |= m.bad;
+            shade_pixel_s<M>(m, K, sd, tf, px, py, r0, r1, r2);
         }
+        if constexpr (std::is_same<M, FastMath>::value) bad |= m.bad;
         s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
         if (STATS && count)
           n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
@@ -1222,31 +1504,76 @@ __global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
       const bool bs = class_pass(policy, std::false_type{}, count);
       return bv | bs;
     };
-    const bool bad = dense_passes(FastMath{}, true);
-    if (__ballot(bad) != 0ull && lane == 0) s_flag = 1u;
-    __syncthreads();
-    if (s_flag) { // workgroup-uniform
+    bool skip_write = false;
+    if constexpr (MODE == 2) {
       if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
-      dense_passes(IeeeMath{}, false);
+      dense_passes(IeeeMath{}, true);
       __syncthreads();
+    } else {
+      // First with the optimistic FastMath; a tile where any operand left the fast range (degenerate normals, a light
+      // straight above a pixel, ...) is shaded again with the IEEE expansions.
+      const bool bad = dense_passes(FastMath{}, true);
+      if (__ballot(bad) != 0ull && lane == 0) s_flag = 1u;
+      __syncthreads();
+      if (s_flag) { // workgroup-uniform
+        if constexpr (MODE == 0) { // hand the tile to the generic build
+          if (tid == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = f * tpf + e;
+          skip_write = true;
+        } else {
+          if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
+          dense_passes(IeeeMath{}, false);
+          __syncthreads();
+        }
+      }
     }
 
     // ---- 3. coalesced write-out of the three colour planes ----------------------------------------------------------
-    C0 = *reinterpret_cast<const float4 *>(&s_c[0][p0]);
-    C1 = *reinterpret_cast<const float4 *>(&s_c[1][p0]);
-    C2 = *reinterpret_cast<const float4 *>(&s_c[2][p0]);
-    if (full) {
-      store_nt(gz + plane, C0);
-      store_nt(gz + 2 * plane, C1);
-      store_nt(gz + 3 * plane, C2);
-    } else if (in_tile) {
+    if (!skip_write) {
+      C0 = *reinterpret_cast<const float4 *>(&s_c[0][p0]);
+      C1 = *reinterpret_cast<const float4 *>(&s_c[1][p0]);
+      C2 = *reinterpret_cast<const float4 *>(&s_c[2][p0]);
+      if (full) {
+        store_nt(gz + plane, C0);
+        store_nt(gz + 2 * plane, C1);
+        store_nt(gz + 3 * plane, C2);
+      } else if (in_tile) {
 #define SRZ_ST(K_, M)                                                                                                  \
   if (x4 + K_ <= tx1) gz[plane + K_] = C0.M, gz[2 * plane + K_] = C1.M, gz[3 * plane + K_] = C2.M;
-      SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+        SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
+      }
     }
     __syncthreads(); // LDS is reused by the next tile of this persistent workgroup
+  };
+
+  // The persistent grid walks VIRTUAL workgroups v = (group of 8 frames, lane j, frame within the group): v shades every
+  // S-th entry of its frame's work list from entry j.  Frame-in-group is the fastest index, so physical workgroup b
+  // (on XCD b % 8) shades frame f with f % 8 == b % 8 — the XCD that rasterised it, whose L2 holds its z / owner ids —
+  // and the ~1000 resident workgroups cover only a group or two of frames at a time (triangles + ids stay L2-resident;
+  // dealing v over ALL frames at once thrashes L2: +10 % kernel time; dropping the XCD affinity: +5..12 %).
+  const uint32_t F = a.n_frames, S = a.shade_split;
+  const uint32_t gsz = F < 8u ? F : 8u; // (fewer than 8 frames: every XCD works on all of them)
+  const uint32_t n_virtual = ((F + gsz - 1u) / gsz) * gsz * S;
+  for (uint32_t v = blockIdx.x; v < ((FAST || a.force_generic || a.any_generic) ? n_virtual : 0u); v += gridDim.x) {
+    const uint32_t r = v % (gsz * S), f = (v / (gsz * S)) * gsz + r % gsz, j = r / gsz;
+    if (f >= F) continue;
+    const bool frame_fast = !a.force_generic && ((as_const(a.frames) + f)->flags & FD_FAST_SHADE) != 0u;
+    if (frame_fast != FAST) continue; // the other build's frame
+    const uint32_t n_work = as_const(a.work_count)[f];
+    for (uint32_t w = j; w < n_work; w += S) {
+      const uint32_t e = as_const(a.worklist)[(size_t)f * tpf + w];
+      if constexpr (FAST)
+        shade_tile(f, e, std::integral_constant<int, 0>{});
+      else
+        shade_tile(f, e, std::integral_constant<int, 1>{});
+    }
   }
+  if constexpr (!FAST) { // the tiles the FAST build handed back (it ran before this kernel on the same stream)
+    const uint32_t n_redo = *as_const(a.redo_count);
+    for (uint32_t i = blockIdx.x; i < n_redo; i += gridDim.x) {
+      const uint32_t x = as_const(a.redo_list)[i];
+      shade_tile(x / tpf, x % tpf, std::integral_constant<int, 2>{});
+    }
   }
   if (STATS) {
     for (int o = 32; o > 0; o >>= 1) {
@@ -1384,15 +1711,11 @@ void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool sta
     hipLaunchKernelGGL(k_setup<false>, grid, dim3(256), 0, s, a, bb);
 }
 
-void launch_bands(const RenderArgs &a, RasterRec *band_recs, uint32_t *band_count, int n_frames, uint32_t max_local_bands,
-                  uint32_t max_tris, hipStream_t s) {
-  if (n_frames <= 0 || max_local_bands == 0) return;
-  dim3 grid(max_local_bands, n_frames);
-  const uint32_t n_chunks = (max_tris + 63) / 64;
-  const uint32_t cap = n_chunks < 1 ? 1 : (n_chunks > (uint32_t)BANDS_MAX_CHUNKS ? (uint32_t)BANDS_MAX_CHUNKS : n_chunks);
-  const int waves = n_chunks <= 256 ? 4 : (n_chunks <= 1024 ? 8 : BANDS_MAX_WAVES);
-  const size_t lds = sizeof(uint32_t) * (3u * (size_t)cap + 256u * waves + 2u + a.mask_words);
-  hipLaunchKernelGGL(k_bands, grid, dim3(64 * waves), lds, s, a, band_recs, band_count, cap);
+void launch_bin(const RenderArgs &a, int n_frames, hipStream_t s) {
+  if (n_frames <= 0 || a.n_local_bands == 0) return;
+  const uint32_t groups = ((uint32_t)n_frames + 7u) / 8u;
+  const size_t lds = sizeof(uint32_t) * (3u * (size_t)a.tiles_x + 128u * BIN_WAVES + 4u);
+  hipLaunchKernelGGL(k_bin, dim3(groups * 8u * a.n_local_bands), dim3(64 * BIN_WAVES), lds, s, a);
 }
 
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s) {
@@ -1407,31 +1730,39 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
   hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(256), 0, s, a);
 }
 
-void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, hipStream_t s) {
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s) {
   if (max_tiles == 0) return;
-  dim3 grid(max_tiles < 4096u ? max_tiles : 4096u); // persistent: workgroups stride over the worklist
-  if (stats)
-    hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), 0, s, a);
+  dim3 grid(max_tiles < 4096u ? max_tiles : 4096u); // persistent: workgroups stride over the worklists
+  if (stats) { // (counting runs shade every frame with the generic build: force_generic)
+    hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), 0, s, a);
+    return;
+  }
+  if (any_fast) hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(256), 0, s, a);
+  // the generic build also serves the tiles the FAST build hands back: when no frame is generic that is normally
+  // nothing, and a small grid does
+  dim3 ggrid(any_generic ? grid.x : (grid.x < 128u ? grid.x : 128u));
+  hipLaunchKernelGGL((k_shade<false, false>), ggrid, dim3(256), 0, s, a);
 }
 
-void launch_raster(const RenderArgs &a, int n_frames, uint32_t max_local_bands, int width, bool stats, hipStream_t s) {
-  if (n_frames <= 0 || max_local_bands == 0) return;
+void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s) {
+  if (n_frames <= 0 || a.n_local_bands == 0) return;
   static bool once = false;
   if (!once && getenv("SRZ_DEBUG")) {
     once = true;
     int nb = 0, ns = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raster<false>, 64 * RASTER_WAVES, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, k_shade<false>, 256, 0);
-    fprintf(stderr, "[srz] occupancy: k_raster %d WGs/CU (x%d waves), k_shade %d WGs/CU\n", nb, RASTER_WAVES, ns);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raster, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, k_shade<false, true>, 256, 0);
+    fprintf(stderr, "[srz] occupancy: k_raster %d waves/CU, k_shade %d WGs/CU\n", nb, ns);
   }
   const uint32_t groups = ((uint32_t)n_frames + 7u) / 8u;
-  dim3 grid(groups * 8u * a.n_local_bands * a.tiles_x);
+  const uint32_t tiles = groups * 8u * a.n_local_bands * a.tiles_x;
+  hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(64), 0, s, a);
+  // the ordered rasteriser for whatever k_raster listed (normally nothing: its waves read a zero and leave)
+  const uint32_t slow_grid = (stats || a.force_ordered) ? (tiles < 4096u ? tiles : 4096u) : (tiles < 256u ? tiles : 256u);
   if (stats)
-    hipLaunchKernelGGL(k_raster<true>, grid, dim3(64 * RASTER_WAVES), 0, s, a);
+    hipLaunchKernelGGL(k_raster_slow<true>, dim3(slow_grid), dim3(64), 0, s, a);
   else
-    hipLaunchKernelGGL(k_raster<false>, grid, dim3(64 * RASTER_WAVES), 0, s, a);
+    hipLaunchKernelGGL(k_raster_slow<false>, dim3(slow_grid), dim3(64), 0, s, a);
 }
 
 void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s) {

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_debug_timeline", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch"]
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch"]
 
 
 class SrzError(RuntimeError):
@@ -64,7 +64,6 @@ def lib():
         L.srz_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.srz_verify_fastmath.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_verify_fastdiv.argtypes = [vp, C.POINTER(C.c_uint64)]
-        L.srz_debug_timeline.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_int]
         _lib = L
     return _lib
 
@@ -199,14 +198,6 @@ class Context:
         out = (C.c_uint64 * 3)()
         self._check(lib().srz_verify_fastdiv(self.h, out))
         return [int(x) for x in out]
-
-    def debug_timeline(self, n_tiles, arm):
-        if arm:
-            self._check(lib().srz_debug_timeline(self.h, None, n_tiles, 1))
-            return None
-        out = np.zeros((n_tiles, 4), np.uint64)
-        self._check(lib().srz_debug_timeline(self.h, out.ctypes.data, n_tiles, 0))
-        return out
 
     def debug_counters(self):
         out = (C.c_uint64 * 32)()

@@ -4,8 +4,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault('SRZ_DEBUG_FLAGS', '1')
-
 import conftest  # noqa: F401  (sys.path)
 import numpy as np
 import torch
@@ -17,7 +15,7 @@ from srz import abi
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-dbg = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
+dbg = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0  # extra render flags, e.g. 4 = ORDERED_RASTER
 BASE_FLAGS = int(os.environ.get('PROBE_FLAGS', str(abi.FUSED_CLEAR)), 0)
 builder = {2: scenes.config2, 3: scenes.config3, 4: scenes.config4, 5: scenes.config5}[cfg]
 t0 = time.time()
@@ -35,8 +33,6 @@ ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
 fs = ctx.frameset(frames)
 st = fs.stats()
 print("stats", st)
-dbg_c = ctx.debug_counters()
-print("dbg cycles A,B,C,maxwave,shade_calls,blocks:", dbg_c[7:13])
 out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 ctx.set_kernel_timing(not os.environ.get('PROBE_NO_TIMING'))

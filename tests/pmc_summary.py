@@ -5,7 +5,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
     if "<true>" in n: continue
-    for k in ("k_setup", "k_bands", "k_raster", "k_clear", "k_shade"):
-        if k in n: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k in ("k_setup", "k_bin", "k_raster_slow", "k_raster", "k_clear", "k_shade", "k_vertex"):
+        if k in n:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            break
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v) / 1e6, 2) for c, v in sorted(d.items())})

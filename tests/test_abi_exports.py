@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libsrz.so does not export {name}"
     for name in srz.EXPORTS:
         assert name in declared_functions()
-    assert lib.srz_abi_version() == 1
+    assert lib.srz_abi_version() == 2
 
 
 def test_struct_sizes_match_the_header():

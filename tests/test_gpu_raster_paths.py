@@ -1,0 +1,146 @@
+"""-m gpu: the two rasterisers behind the C ABI against the CPU oracle.
+
+k_raster resolves visibility ORDER-INDEPENDENTLY (one 64-bit depth | tie-break key per pixel, LDS min); what the keys
+cannot express — a NaN depth that passes a scalar-tail test, a final depth of ±0, a band whose records did not fit the
+pool — is handed to k_raster_slow, the reference's ordered triangle walk (src/Rasterizer.cpp:199-236).  Both must give
+the oracle's framebuffer bit for bit; SRZ_ORDERED_RASTER forces the ordered one everywhere."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from srz import abi
+from test_oracle_kat import frame, tri
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import srz
+    c = srz.Context(0)
+    c.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    yield c
+    c.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def same(gpu, ref, what):
+    for p in range(4):
+        bad = bits(gpu[p]) != bits(ref[p])
+        assert not bad.any(), f"{what}: plane {p} differs at {int(bad.sum())} pixels, first {np.argwhere(bad)[:4].tolist()}"
+
+
+def both_paths(ctx, orc, f_builder, planes_init=None, what=""):
+    """draw through the order-independent rasteriser and through the ordered one; both must equal the oracle."""
+    for extra in (0, abi.ORDERED_RASTER):
+        f = f_builder(extra)
+        clone = (lambda: None) if planes_init is None else (lambda: tuple(p.copy() for p in planes_init))
+        rc, ref, rst = orc.draw(f, clone())
+        assert rc == 0
+        gpu, gst = ctx.draw(f, clone(), want_stats=True)
+        assert gst == rst, (what, extra, gst, rst)
+        same(gpu, ref, f"{what} flags+={extra}")
+
+
+@pytest.mark.parametrize("shader", [abi.SHADER_TEXTURE, abi.SHADER_NORMAL])
+def test_ordered_flag_equals_oracle_on_spot(ctx, orc, shader):
+    both_paths(ctx, orc, lambda extra: scenes.config2(5, size=512, shader=shader, flags=abi.FUSED_CLEAR | extra), what="spot512")
+
+
+def soup(seed, n, w, h, zs, big=False):
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, abi.TRI_DTYPE)
+    c = rng.uniform(-8, [w + 8, h + 8], (n, 1, 2))
+    r = rng.uniform(1, 70 if big else 24, (n, 1, 1))
+    xy = c + rng.uniform(-1, 1, (n, 3, 2)) * r
+    xy = np.round(xy * 4) / 4 if seed % 2 else xy  # half the seeds: quarter-pixel vertices → exact edge hits and ties
+    t["pos"][:, :, :2] = xy
+    t["pos"][:, :, 2] = rng.choice(zs, (n, 1)) if seed % 3 == 0 else rng.choice(zs, (n, 3))
+    nn = rng.normal(size=(n, 3, 3))
+    t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+    t["uv"] = rng.uniform(0, 1, (n, 3, 2))
+    return t
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_zero_and_signed_zero_depths(ctx, orc, seed):
+    """depths drawn from {-0, +0, tiny, 1}: -0 == +0 as floats but not as keys — the ±0 pixels must take the ordered path"""
+    zs = np.array([0.0, -0.0, 1e-30, -1e-30, 1.0], np.float32)
+    t = soup(seed, 60, 96, 80, zs)
+    both_paths(ctx, orc, lambda extra: frame(t, 96, 80, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | extra), what=f"zero-z seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_negative_and_huge_depths(ctx, orc, seed):
+    zs = np.array([-5.0, -1e30, 3e38, -3e38, 7.0, 7.0, 0.25], np.float32)
+    t = soup(seed + 10, 80, 130, 70, zs, big=True)
+    both_paths(ctx, orc, lambda extra: frame(t, 130, 70, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | extra), what=f"neg/huge seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_incoming_planes_with_nan_inf_and_zero_depths(ctx, orc, seed):
+    """accumulate mode: the incoming z plane holds NaN / ±inf / ±0 / ordinary depths.  A NaN in the buffer blocks every
+    V fragment and admits every S fragment (src/Rasterizer.cpp:334,475)."""
+    w, h = 100, 72
+    rng = np.random.default_rng(100 + seed)
+    z = rng.choice(np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 5.0, 50.0, 60.0], np.float32), (h, w)).astype(np.float32)
+    init = (z, rng.uniform(0, 255, (h, w)).astype(np.float32), rng.uniform(0, 255, (h, w)).astype(np.float32),
+            rng.uniform(0, 255, (h, w)).astype(np.float32))
+    t = soup(seed + 20, 70, w, h, np.array([5.0, 50.0, 55.0, 60.0, 0.0], np.float32))
+    both_paths(ctx, orc, lambda extra: frame(t, w, h, shader=abi.SHADER_NORMAL, flags=extra), planes_init=init, what=f"incoming seed {seed}")
+
+
+def test_depth_ties_between_many_fragments(ctx, orc):
+    """every triangle at the same depth: per pixel the LAST scalar-tail fragment wins if there is one, else the FIRST
+    8-wide one — the tie-break half of the key"""
+    t = soup(7, 120, 128, 96, np.array([42.0], np.float32), big=True)
+    both_paths(ctx, orc, lambda extra: frame(t, 128, 96, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | extra), what="ties")
+
+
+def test_unified_flag_both_paths(ctx, orc):
+    t = soup(3, 90, 128, 96, np.array([1.0, 2.0, 3.0], np.float32), big=True)
+    both_paths(ctx, orc, lambda extra: frame(t, 128, 96, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | abi.UNIFIED | extra), what="unified")
+
+
+def test_pool_overflow_then_growth(ctx, orc):
+    """A few screen-filling triangles make far more (triangle, tile) pairs than the first guess of the record pool: the
+    first render serves the bands that do not fit through the ordered rasteriser, the next one finds the pool grown.
+    Both must equal the oracle."""
+    w = h = 1024
+    n = 24
+    t = np.zeros(n, abi.TRI_DTYPE)
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
+    nn = rng.normal(size=(n, 3, 3))
+    t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+    f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
+    rc, ref, _ = orc.draw(f)
+    assert rc == 0
+    fs = ctx.frameset([f])
+    out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+    for it in range(3):
+        out.fill_(-1.0)
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        same(out[0].cpu().numpy(), ref, f"pool overflow, render {it}")
+    fs.close()
+
+
+def test_many_small_frames_fill_every_subpool(ctx, orc):
+    """enough frames that the pool is split into several sub-pools; every frame must still come out right"""
+    frames = [scenes.config2(i, size=256) for i in range(40)]
+    fs = ctx.frameset(frames)
+    out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+    for it in range(2):
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in (0, 9, 17, 39):
+        rc, ref, _ = orc.draw(frames[i])
+        same(got[i], ref, f"frame {i}")
+    fs.close()
