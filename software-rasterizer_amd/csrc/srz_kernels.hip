@@ -830,7 +830,7 @@ __device__ __forceinline__ float bperm_f(int addr, float v) {
 }
 __device__ __forceinline__ uint32_t bperm_u(int addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v); }
 
-__global__ __launch_bounds__(64) void k_raster(RenderArgs a) {
+__global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long s_key[TILE * KEY_STRIDE];
 
   const int lane = threadIdx.x & 63;
@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 //   generic  every other frame with per-pixel generality (any shader, any light count, any exponent), FastMath first and
 //            the IEEE expansions for a tile that needs them; then the tiles the FAST build handed back, IEEE at once.
 template <bool STATS, bool FAST>
-__global__ __launch_bounds__(256, SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
+__global__ __launch_bounds__(256, FAST ? 5 : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];

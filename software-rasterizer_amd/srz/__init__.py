@@ -12,7 +12,7 @@ from . import abi
 from .abi import Frame  # noqa: F401
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libsrz.so")
+LIB_PATH = os.environ.get("SRZ_LIB_PATH", os.path.join(_PKG, "libsrz.so"))  # (override: A/B of dev builds)
 _lib = None
 
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
