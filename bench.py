@@ -2,19 +2,23 @@
 """bench.py — frames/s (+ Mfragments/s) of the MI355X raster + fragment-shade stage on BASELINE.json's configs[1]
 (spot_triangulated_good.obj, 1024x1024, TEXTURE shader + 2 point lights).
 
-A "step" = one pass of the hot path (setup → band binning → visibility raster → shading) over one batch of F synthetic
-frames per GPU (frame i is the spot mesh rotated by 10*i degrees, the reference's own per-frame variation), inputs
-(post-MVP triangle streams, lights, texture) already resident in HBM, output = the reference's framebuffer layout
-(z + 3 planar float colour planes per frame) in HBM.
+A "step" = one pass of the hot path (setup → tile binning → visibility raster → shading, the fused clear beside them) over
+one batch of F synthetic frames per GPU (frame i is the spot mesh rotated by 10*i degrees, the reference's own per-frame
+variation), inputs (post-MVP triangle streams, lights, texture) already resident in HBM, output = the reference's
+framebuffer layout (z + 3 planar float colour planes per frame) in HBM.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU; every frame's 32-row bands are dealt round-robin to the ranks (srz_set_shard), each rank
-renders its bands of F*N frames (per-GPU pixel work fixed → weak scaling), and an RCCL all-gather over xGMI plus a
-de-interleave copy reassemble every full framebuffer on every rank (the exchange step BASELINE.json's north_star names).
+N = 1 also measures, after the headline config and outside its timed region, the other GPU configs of BASELINE.json
+(configs[2..4], whole frames on one GPU) and configs[1] at scope "draw" (vertex stage timed too): `configs` in the JSON.
 
-Prints ONE JSON line (rank 0).  PyTorch is only plumbing here (device buffers, streams, torch.distributed).
+N > 1: one process per GPU; every frame's 32-row bands are dealt round-robin to the ranks (srz_set_shard), each rank
+renders its bands of F*N frames (per-GPU pixel work fixed → weak scaling), and the exchange north_star names — an RCCL
+all-gather over xGMI behind the C ABI (srz_frameset_allgather) + one HIP de-interleave pass — reassembles every full
+framebuffer on every rank.  The exchange of step k runs on its own stream while step k+1 renders (double-buffered).
+
+Prints ONE JSON line (rank 0).  PyTorch is only plumbing here (device buffers, streams, the rendezvous).
 """
 import argparse
 import json
@@ -27,6 +31,9 @@ sys.path.insert(0, os.path.join(REPO, "software-rasterizer_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_MEASURED_COPY_GBS = 6290.0
+XGMI_LINK_GBS = 153.0  # per link, per direction (7 links per GPU)
+# the other GPU configs of BASELINE.json, whole frames on one GPU: (workload, frames per step, steps)
+EXTRA_CASES = [("spot_bunny_phong_1080p", 64, 10), ("spot_x16_texture_2048", 32, 10), ("spot_x8_overdraw_4096", 16, 10)]
 
 
 def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
@@ -95,6 +102,89 @@ def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
             "host_cpus": ncpu}
 
 
+def pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = q * (len(xs) - 1)
+    lo, hi = int(i), min(int(i) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
+
+
+class Case:
+    """One workload resident on this rank's GPU: frameset, counters, output buffers."""
+
+    def __init__(self, ctx, torch, workload, frames_per_gpu, scope, world, n_out=1):
+        import srz
+        from srz import scenes
+        self.torch, self.ctx, self.name, self.scope, self.world = torch, ctx, workload, scope, world
+        wl = scenes.WORKLOADS[workload]()
+        n_frames = frames_per_gpu * world
+        uniq = [wl.frame(i) for i in range(min(n_frames, 36))]  # 36 distinct rotations (10 deg steps)
+        frames = [uniq[i % len(uniq)] for i in range(n_frames)]
+        wl.upload_textures(ctx)
+        self.tris_per_frame = frames[0].n_tris
+        if scope == "draw":  # same frames, given as meshes + matrices: the device runs the vertex stage every step
+            wl.upload_meshes(ctx)
+            suniq = [wl.scene_frame(i) for i in range(min(n_frames, 36))]
+            frames = [suniq[i % len(suniq)] for i in range(n_frames)]
+        self.fs = ctx.frameset(frames)
+        self.stats = self.fs.stats()  # counting variant of the kernels, run once, outside every timed region
+        self.algo_bytes = self.fs.algorithmic_bytes()
+        self.n_frames, self.frames_per_gpu = n_frames, frames_per_gpu
+        self.out = [torch.empty(self.fs.out_shape, dtype=torch.float32, device="cuda") for _ in range(n_out)]
+
+    def close(self):
+        self.out = None
+        self.fs.close()
+        self.torch.cuda.empty_cache()
+
+
+def time_single_gpu(case, steps, warmup, fence):
+    """W warm-up steps, then EXACTLY K steps bracketed by fences; per-step device times from events on the render stream."""
+    torch, ctx, fs = case.torch, case.ctx, case.fs
+    from srz import abi
+    stream = torch.cuda.Stream()
+    out = case.out[0]
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+        fence()
+        ctx.set_kernel_timing(True)
+        ctx.kernel_time_ms(reset=True)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for k in range(steps):
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+            evs[k + 1].record(stream)
+        fence()
+        dt = time.perf_counter() - t0
+    kt = ctx.kernel_time_ms(reset=True)
+    ctx.set_kernel_timing(False)
+    per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+    return dt, kt, per_step
+
+
+def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
+    fs = case.fs
+    fps = case.n_frames * steps / dt
+    pipeline_s = kt["total_ms"] * 1e-3
+    achieved = case.algo_bytes / pipeline_s / 1e9 if pipeline_s > 0 else 0.0
+    return {
+        "workload": case.name, "scope": case.scope, "width": fs.width, "height": fs.height,
+        "frames_per_step": case.n_frames, "triangles_per_frame": case.tris_per_frame, "steps": steps,
+        "frames_per_sec": fps, "ms_per_step": dt / steps * 1e3,
+        "ms_per_step_p10_median_p90": [pct(per_step, 0.1), pct(per_step, 0.5), pct(per_step, 0.9)] if per_step else None,
+        "us_per_frame_median": (pct(per_step, 0.5) * 1e3 / case.n_frames) if per_step else None,
+        "mfragments_per_sec": frag_total / fs.n_frames * fps / 1e6,
+        "fragments_per_frame": frag_total / fs.n_frames, "visible_pixels_per_frame": vis_total / fs.n_frames,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
+                     "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +198,8 @@ def main():
     ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
                     help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
                          "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1 only: render and exchange back to back on one stream")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: skip the other BASELINE configs / scope draw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     args = ap.parse_args()
@@ -115,7 +207,7 @@ def main():
     import torch
     import torch.distributed as dist
     import srz
-    from srz import abi, parallel, scenes
+    from srz import abi, parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,118 +223,163 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- inputs: built by the product's host layer (C++ Scene / ObjLoader / vertex stage), uploaded once ----------
-    wl = scenes.WORKLOADS[args.workload]()
-    n_frames = args.frames * world
-    uniq = [wl.frame(i) for i in range(min(n_frames, 36))]  # 36 distinct rotations (10 deg steps)
-    frames = [uniq[i % len(uniq)] for i in range(n_frames)]
-    ctx = srz.Context(local_rank, rank, world)
-    wl.upload_textures(ctx)
-    n_tris_frame = frames[0].n_tris
-    if args.scope == "draw":  # same frames, given as meshes + matrices: the device runs the vertex stage every step
-        wl.upload_meshes(ctx)
-        suniq = [wl.scene_frame(i) for i in range(min(n_frames, 36))]
-        frames = [suniq[i % len(suniq)] for i in range(n_frames)]
-    fs = ctx.frameset(frames)
-    stats = fs.stats()  # counting variant of the kernels, run once, outside the timed region
-    if world > 1:
-        st = torch.tensor([stats["fragments"], stats["visible"], stats["shaded"]], dtype=torch.int64, device="cuda")
-        dist.all_reduce(st)
-        frag_total, vis_total = int(st[0]), int(st[1])
-    else:
-        frag_total, vis_total = stats["fragments"], stats["visible"]
-    algo_bytes = fs.algorithmic_bytes()
-
-    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    gathered = full = bgr = None
-    if world > 1:
-        bpr = fs.local_rows // 32
-        if args.exchange == "planes":
-            gathered = torch.empty((world,) + tuple(fs.out_shape), dtype=torch.float32, device="cuda")
-            full = torch.empty((n_frames, 4, bpr * world * 32, fs.width), dtype=torch.float32, device="cuda")
-        else:  # display()'s 8-bit image: one "plane" of W*3 bytes per row
-            bgr = torch.empty((n_frames, 1, fs.local_rows, fs.width * 3), dtype=torch.uint8, device="cuda")
-            gathered = torch.empty((world,) + tuple(bgr.shape), dtype=torch.uint8, device="cuda")
-            full = torch.empty((n_frames, 1, bpr * world * 32, fs.width * 3), dtype=torch.uint8, device="cuda")
-
-    def step():
-        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream)
-        if world > 1:
-            # band b = local_band*world + rank  →  row-major planes (rows beyond `height` are all-gather padding)
-            if args.exchange == "planes":
-                parallel.all_gather_frames(out, world, gathered, full)
-            else:
-                fs.resolve8(out.data_ptr(), bgr.data_ptr(), bgr.numel(), stream)
-                parallel.all_gather_frames(bgr, world, gathered, full)
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.set_kernel_timing(True)
-    ctx.kernel_time_ms(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    kt = ctx.kernel_time_ms(reset=True)
-    ctx.set_kernel_timing(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    ctx = srz.Context(local_rank, rank, world)
+    comm, comm_note = None, None
+    if world > 1:  # the exchange behind the C ABI: RCCL communicator from an id made on rank 0
+        try:
+            ids = [srz.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = srz.Comm(ctx, ids[0], rank, world)
+        except Exception as e:  # noqa: BLE001  (fall back to torch.distributed's RCCL rather than lose the measurement)
+            comm, comm_note = None, f"srz_comm_create failed ({e}); exchange through torch.distributed instead"
 
+    case = Case(ctx, torch, args.workload, args.frames, args.scope, world, n_out=2 if world > 1 else 1)
+    fs, stats = case.fs, case.stats
+    if world > 1:
+        st = torch.tensor([stats["fragments"], stats["visible"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(st)
+        frag_total, vis_total = int(st[0]), int(st[1])
+    else:
+        frag_total, vis_total = stats["fragments"], stats["visible"]
+
+    multi = None
+    if world == 1:
+        dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence)
+    else:
+        # ---- N > 1: render on one stream, exchange (all-gather + de-interleave) on another, double-buffered ------------
+        what = abi.EXCHANGE_PLANES if args.exchange == "planes" else abi.EXCHANGE_BGR8
+        bpr = fs.local_rows // 32
+        if args.exchange == "planes":
+            shard = case.out
+            full_shape, dtype = (case.n_frames, 4, bpr * world * 32, fs.width), torch.float32
+        else:  # display()'s 8-bit image: one "plane" of W*3 bytes per row
+            shard = [torch.empty((case.n_frames, 1, fs.local_rows, fs.width * 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            full_shape, dtype = (case.n_frames, 1, bpr * world * 32, fs.width * 3), torch.uint8
+        gathered = [torch.empty((world,) + tuple(shard[0].shape), dtype=dtype, device="cuda") for _ in range(2)]
+        full = [torch.empty(full_shape, dtype=dtype, device="cuda") for _ in range(2)]
+        rq = parallel.TorchQueue()
+        xq = rq if args.no_overlap else parallel.TorchQueue()
+
+        def render(b):
+            fs.render(case.out[b].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, rq.handle)
+            if args.exchange == "bgr8":
+                fs.resolve8(case.out[b].data_ptr(), shard[b].data_ptr(), shard[b].numel(), rq.handle)
+
+        def exchange(b):
+            if comm is not None:
+                fs.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
+            else:  # (torch.distributed's RCCL on the current = exchange stream, then the HIP de-interleave)
+                dist.all_gather_into_tensor(gathered[b].view(-1), shard[b].reshape(-1))
+                fs.deinterleave(gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
+
+        pipe = parallel.ExchangePipeline(render, exchange, rq, xq)
+        for _ in range(args.warmup):
+            pipe.step()
+        pipe.drain()
+        fence()
+        ctx.set_kernel_timing(True)
+        ctx.kernel_time_ms(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.step()
+        pipe.drain()
+        fence()
+        dt = time.perf_counter() - t0
+        kt = ctx.kernel_time_ms(reset=True)
+        ctx.set_kernel_timing(False)
+        per_step = []
+        # the exchange alone (no render beside it), same buffers: what the overlap has to hide
+        fence()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            xq.submit(lambda b=k % 2: exchange(b))
+        xq.drain()
+        fence()
+        x_alone = (time.perf_counter() - t1) / args.steps * 1e3
+        tt = torch.tensor([dt, x_alone * 1e-3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, x_alone = float(tt[0]), float(tt[1]) * 1e3
+        step_ms = dt / args.steps * 1e3
+        shard_bytes = shard[0].numel() * shard[0].element_size()
+        multi = {"exchange": args.exchange, "behind_c_abi": comm is not None, "overlapped": not args.no_overlap,
+                 "step_ms": step_ms, "render_ms_per_step": kt["total_ms"], "exchange_alone_ms_per_step": x_alone,
+                 "hidden_ms_per_step": max(0.0, kt["total_ms"] + x_alone - step_ms),
+                 "bytes_sent_per_rank_per_step": shard_bytes, "bytes_received_per_rank_per_step": (world - 1) * shard_bytes,
+                 "predicted_exchange_ms_at_xgmi_peak": shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3,
+                 "note": "exchange = srz_frameset_allgather: ncclAllGather of every rank's band shard (each rank sends its shard "
+                         "once to each of the N-1 peers, one xGMI link per peer: time >= shard bytes / 153 GB/s) + one HIP "
+                         "de-interleave pass; step k's exchange runs while step k+1 renders"}
+        if comm_note:
+            multi["fallback"] = comm_note
+
+    res = None
     if rank == 0:
-        fps = n_frames * args.steps / dt
-        pipeline_s = kt["total_ms"] * 1e-3
-        achieved = algo_bytes / pipeline_s / 1e9 if pipeline_s > 0 else 0.0
-        traffic = None
+        rec = case_record(case, args.steps, dt, kt, per_step, frag_total, vis_total)
+        traffic, traffic_src = None, None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and world == 1:
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
+                t = json.load(open(tfile)).get(args.workload, {})
+                if t.get("frames_per_launch") == case.n_frames and args.scope == "raster":
+                    traffic, traffic_src = t.get("hbm_bytes_per_launch"), f"profiles/{t.get('from')}"
+            except Exception:  # noqa: BLE001
                 traffic = None
+        roof = rec["roofline"]
+        roof.update({"traffic": traffic,
+                     "traffic_source": (f"{traffic_src}: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 --pmc passes of this command, per launch "
+                                        "(not measured in this run)") if traffic else None,
+                     "frac_of_measured_copy_6290": roof["achieved"] / HBM_MEASURED_COPY_GBS,
+                     "kernel": "hot path = k_setup + k_bin + k_raster (+ k_raster_slow) + k_shade in line, k_clear beside k_raster/k_shade "
+                               "on a second stream (one launch each per step)",
+                     "launches_timed": kt["launches"],
+                     "note": "rank 0's shard; HIP events on the launch stream; algorithmic bytes = "
+                             "16*W*rows + 96*N_tri + 24*N_lights + min(3*texW*texH, 3*textured_px) per frame"})
         res = {
-            "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "frames_per_sec", "value": rec["frames_per_sec"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": fs.width, "height": fs.height,
-                       "frames_per_step": n_frames, "frames_per_step_per_gpu": args.frames,
-                       "triangles_per_frame": n_tris_frame, "lights": 2, "scope": args.scope,
+                       "frames_per_step": case.n_frames, "frames_per_step_per_gpu": args.frames,
+                       "triangles_per_frame": case.tris_per_frame, "lights": 2, "scope": args.scope,
                        "sharding": "whole frames on 1 GPU" if world == 1 else
                        f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {args.exchange} + de-interleave (timed)"},
-            "mfragments_per_sec": frag_total / fs.n_frames * fps / 1e6,
-            "fragments_per_frame": frag_total / fs.n_frames, "visible_pixels_per_frame": vis_total / fs.n_frames,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
-                         "kernel": "hot path = k_setup + k_bands + k_raster + k_shade in line, k_clear beside k_raster/k_shade on a second stream (one launch each per step)",
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "launch_ms": kt["total_ms"], "k_setup_bands_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"],
-                         "k_shade_ms": kt["shade_ms"], "launches_timed": kt["launches"],
-                         "note": "rank 0's shard; HIP events on the launch stream; algorithmic bytes = "
-                                 "16*W*rows + 96*N_tri + 24*N_lights + min(3*texW*texH, 3*textured_px) per frame"},
+            "mfragments_per_sec": rec["mfragments_per_sec"], "fragments_per_frame": rec["fragments_per_frame"],
+            "visible_pixels_per_frame": rec["visible_pixels_per_frame"],
+            "ms_per_step_p10_median_p90": rec["ms_per_step_p10_median_p90"], "us_per_frame_median": rec["us_per_frame_median"],
+            "roofline": roof,
             "reference_published": {"fps": 58.6, "note": "README.md:619-629, i7-12800HX/MSVC, spot+crate 5-mesh scene, "
                                     "draw() incl. vertex stage — different workload/hardware, not reproducible here"},
         }
-        if world > 1:  # report the render and the exchange separately (rank 0's view)
-            step_ms = dt / args.steps * 1e3
-            res["multi_gpu"] = {"render_ms_per_step": kt["total_ms"], "exchange_ms_per_step": max(0.0, step_ms - kt["total_ms"]),
-                                "exchange": args.exchange,
-                                "bytes_received_per_rank_per_step": (world - 1) * (out.numel() * 4 if args.exchange == "planes" else bgr.numel()),
-                                "note": "exchange = RCCL all-gather of every rank's band shard + de-interleave to row-major; "
-                                        "xGMI-bound by construction (every rank receives (N-1)/N of every framebuffer)"}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_budget_s)
+        if multi:
+            res["multi_gpu"] = multi
+    case.close()
+
+    # ---- N = 1: the other GPU configs of BASELINE.json + configs[1] at scope draw, each outside the headline's timed region
+    if world == 1 and not args.no_extras:
+        extras = []
+        todo = [(w, f, s, "raster") for (w, f, s) in EXTRA_CASES if w != args.workload]
+        todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster"))
+        for (w, f, s, scope) in todo:
+            try:
+                c = Case(ctx, torch, w, f, scope, 1)
+                d, k, ps = time_single_gpu(c, s, 2, fence)
+                extras.append(case_record(c, s, d, k, ps, c.stats["fragments"], c.stats["visible"]))
+                c.close()
+            except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+                extras.append({"workload": w, "scope": scope, "error": str(e)})
+        res["configs"] = extras
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_budget_s)
+    if rank == 0:
         print(json.dumps(res))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -183,7 +183,9 @@ int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_f
  *     [frame][plane: z,c0,c1,c2][local_rows][width]   (float32)
  * where local_rows = srz_frameset_local_rows() (= height for an unsharded ctx, else
  * bands_per_rank*32, zero-padded).  d_out is a DEVICE pointer (e.g. a torch tensor's data_ptr),
- * stream a hipStream_t (NULL = the ctx's own stream).  The call is asynchronous on that stream. */
+ * stream a hipStream_t (NULL = the ctx's own non-blocking stream; pass SRZ_STREAM_NULL for HIP's null stream:
+ * work on the ctx's stream is NOT ordered against the null stream).  The call is asynchronous on that stream. */
+#define SRZ_STREAM_NULL ((void *)(intptr_t)-1)
 int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out);
 /* Same, but the frames are given as meshes + matrices: every srz_frameset_render first runs the vertex stage on the
  * device (k_vertex) to produce the post-MVP stream, i.e. it times the reference's whole draw(). */
@@ -207,6 +209,28 @@ int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_pl
  * on the context's own stream (ordered against srz_target_draw / renders submitted there, no host synchronisation);
  * renders of this set submitted on a caller-provided stream must be ordered against it by the caller. */
 int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *frames, int n_frames);
+
+/* ---- multi-GPU exchange: the band shards of every rank → full row-major frames on every rank ------------------------
+ * One process per GPU.  Rank 0 makes an id (srz_comm_unique_id), the host program hands the 128 bytes to every rank
+ * (MPI, torch.distributed, a file), and every rank calls srz_comm_create, which builds the RCCL communicator (librccl is
+ * loaded on first use) and sets the ctx's shard like srz_set_shard(ctx, rank, world).
+ * srz_frameset_allgather = ncclAllGather over xGMI of this rank's shard (what srz_frameset_render / _resolve8 wrote:
+ * [frame][4 planes | 1][local_rows][W x 4 | W x 3 bytes]) into d_gathered (world x shard bytes), then one HIP pass that
+ * de-interleaves the round-robin bands into d_full = [frame][planes][bands_per_rank*world*32 rows][row] (rows >= height
+ * are padding).  Asynchronous on `stream`; to overlap the exchange of step k with the render of step k+1 give the two
+ * different streams and shard buffers and order them with events (bench.py does).  srz_frameset_deinterleave is the second
+ * half alone (for a host program that brings its own collective). */
+#define SRZ_EXCHANGE_PLANES 0 /* the 4 float planes, 16 bytes per pixel */
+#define SRZ_EXCHANGE_BGR8 1   /* display()'s resolved image, 3 bytes per pixel */
+typedef struct srz_comm srz_comm;
+int srz_comm_unique_id(uint8_t *out128);
+int srz_comm_create(srz_ctx *ctx, const uint8_t *id128, int rank, int world, srz_comm **out);
+void srz_comm_destroy(srz_ctx *ctx, srz_comm *comm);
+size_t srz_frameset_exchange_bytes(const srz_ctx *ctx, const srz_frameset *fs, int what); /* bytes of this rank's shard */
+int srz_frameset_allgather(srz_ctx *ctx, srz_comm *comm, const srz_frameset *fs, const void *d_shard, void *d_gathered,
+                           void *d_full, int what, void *stream);
+int srz_frameset_deinterleave(srz_ctx *ctx, const srz_frameset *fs, const void *d_gathered, void *d_full, int what,
+                              void *stream);
 
 /* ---- device-resident framebuffer = RenderingPipeline's m_zBuffer + m_channels kept in HBM between calls ----------
  * clear(Color|Depth) immediately followed by a draw costs nothing (fused into the raster kernel); planes come back to

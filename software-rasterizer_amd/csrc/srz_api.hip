@@ -1,5 +1,7 @@
 // srz_api.hip — the C ABI declared in include/srz.h (host side: contexts, framesets, uploads, launches).
 // No CPU fallback exists: without a usable gfx950 device every compute entry point returns SRZ_E_NODEVICE.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -101,6 +103,13 @@ struct srz_frameset {
 };
 
 namespace {
+
+// `stream` arguments of the C ABI: NULL = the ctx's own (non-blocking) stream, SRZ_STREAM_NULL = HIP's null stream, else a
+// hipStream_t
+hipStream_t pick_stream(const srz_ctx *ctx, void *stream) {
+  if (!stream) return ctx->stream;
+  return stream == SRZ_STREAM_NULL ? (hipStream_t) nullptr : (hipStream_t)stream;
+}
 
 int fail(srz_ctx *ctx, int code, const std::string &msg) {
   if (ctx)
@@ -875,7 +884,7 @@ int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_
   if (out_bytes < srz_frameset_out_bytes(ctx, fs)) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: output buffer too small");
   if (((uintptr_t)d_out & 15u) != 0) return fail(ctx, SRZ_E_INVALID, "srz_frameset_render: output must be 16-byte aligned");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t s = pick_stream(ctx, stream);
   flags &= SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER;
   return render_impl(ctx, fs, (float *)d_out, flags, s, false);
 }
@@ -887,7 +896,7 @@ int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_pl
   if (bgr8_bytes < (size_t)fs->n_frames * fs->local_rows * (size_t)fs->width * 3) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: output too small");
   if (((uintptr_t)d_planes & 15u) || ((uintptr_t)d_bgr8 & 3u)) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: misaligned buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t s = pick_stream(ctx, stream);
   launch_resolve8((const float *)d_planes, (uint8_t *)d_bgr8, (uint32_t)fs->n_frames, fs->local_rows, (uint32_t)fs->width,
                   4ull * fs->local_rows * (uint64_t)fs->width, s);
   HIP_TRY(ctx, hipGetLastError());
@@ -979,6 +988,138 @@ int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n) {
   if (!ctx || !out) return SRZ_E_INVALID;
   for (int i = 0; i < n && i < ST_COUNT; ++i) out[i] = ctx->dbg[i];
   return ST_COUNT;
+}
+
+/* ---- multi-GPU: the band exchange on RCCL ---------------------------------------------------------------------------
+ * librccl is loaded on first use (a single-GPU program never needs it); if the process already holds a copy (PyTorch
+ * ships its own), that one is used. */
+} // extern "C"
+namespace {
+struct RcclApi {
+  void *handle = nullptr;
+  struct UniqueId { char internal[128]; };
+  int (*GetUniqueId)(UniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string error;
+};
+RcclApi &rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api;
+  tried = true;
+  const char *names[] = {"librccl.so", "librccl.so.1"};
+  for (const char *n : names)
+    if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); // a copy the process already loaded
+  for (const char *n : names)
+    if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!api.handle) api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!api.handle) {
+    api.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+    return api;
+  }
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) api.error = "librccl lacks the nccl* entry points";
+  return api;
+}
+std::string rccl_err(int rc) {
+  RcclApi &r = rccl();
+  return r.GetErrorString ? r.GetErrorString(rc) : ("rccl error " + std::to_string(rc));
+}
+} // namespace
+extern "C" {
+
+struct srz_comm {
+  void *comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+int srz_comm_unique_id(uint8_t *out128) {
+  if (!out128) return fail(nullptr, SRZ_E_INVALID, "srz_comm_unique_id: out is NULL");
+  RcclApi &r = rccl();
+  if (!r.error.empty()) return fail(nullptr, SRZ_E_NODEVICE, "srz_comm_unique_id: " + r.error);
+  RcclApi::UniqueId id;
+  const int rc = r.GetUniqueId(&id);
+  if (rc != 0) return fail(nullptr, SRZ_E_NODEVICE, "ncclGetUniqueId: " + rccl_err(rc));
+  std::memcpy(out128, id.internal, 128);
+  return SRZ_OK;
+}
+
+int srz_comm_create(srz_ctx *ctx, const uint8_t *id128, int rank, int world, srz_comm **out) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, SRZ_E_INVALID, "srz_comm_create: bad arguments");
+  *out = nullptr;
+  RcclApi &r = rccl();
+  if (!r.error.empty()) return fail(ctx, SRZ_E_NODEVICE, "srz_comm_create: " + r.error);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  srz_comm *c = new (std::nothrow) srz_comm();
+  if (!c) return fail(ctx, SRZ_E_NOMEM, "srz_comm_create: out of host memory");
+  RcclApi::UniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  const int rc = r.CommInitRank(&c->comm, world, id, rank);
+  if (rc != 0) {
+    delete c;
+    return fail(ctx, SRZ_E_NODEVICE, "ncclCommInitRank: " + rccl_err(rc));
+  }
+  c->rank = rank, c->world = world;
+  ctx->shard_rank = rank, ctx->shard_world = world; // = srz_set_shard: framesets created from now on are this rank's bands
+  *out = c;
+  return SRZ_OK;
+}
+
+void srz_comm_destroy(srz_ctx *ctx, srz_comm *c) {
+  if (!c) return;
+  if (ctx) (void)hipSetDevice(ctx->device), (void)hipDeviceSynchronize();
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  delete c;
+}
+
+size_t srz_frameset_exchange_bytes(const srz_ctx *ctx, const srz_frameset *fs, int what) {
+  if (!fs) return 0;
+  const size_t row = what == SRZ_EXCHANGE_BGR8 ? (size_t)fs->width * 3u : (size_t)fs->width * sizeof(float);
+  const size_t planes = what == SRZ_EXCHANGE_BGR8 ? 1u : 4u;
+  return (size_t)fs->n_frames * planes * fs->local_rows * row;
+}
+
+int srz_frameset_deinterleave(srz_ctx *ctx, const srz_frameset *fs, const void *d_gathered, void *d_full, int what, void *stream) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!fs || !d_gathered || !d_full || (what != SRZ_EXCHANGE_PLANES && what != SRZ_EXCHANGE_BGR8))
+    return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: bad arguments");
+  if (fs->shard_world == 1) return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: the frameset is not sharded");
+  const uint32_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (uint32_t)fs->width * 3u : (uint32_t)fs->width * 4u;
+  if (row_bytes & 3u) return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: rows must be a multiple of 4 bytes");
+  if (((uintptr_t)d_gathered | (uintptr_t)d_full) & 3u) return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: misaligned buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  launch_deinterleave(d_gathered, d_full, (uint32_t)fs->shard_world, (uint32_t)fs->n_frames * (what == SRZ_EXCHANGE_BGR8 ? 1u : 4u),
+                      fs->bands_per_rank, row_bytes, s);
+  HIP_TRY(ctx, hipGetLastError());
+  return SRZ_OK;
+}
+
+int srz_frameset_allgather(srz_ctx *ctx, srz_comm *c, const srz_frameset *fs, const void *d_shard, void *d_gathered, void *d_full,
+                           int what, void *stream) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!c || !fs || !d_shard || !d_gathered || !d_full) return fail(ctx, SRZ_E_INVALID, "srz_frameset_allgather: null argument");
+  if (fs->shard_world != c->world || fs->shard_rank != c->rank)
+    return fail(ctx, SRZ_E_INVALID, "srz_frameset_allgather: the frameset was not created under this communicator's shard");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const size_t bytes = srz_frameset_exchange_bytes(ctx, fs, what);
+  if (bytes == 0) return fail(ctx, SRZ_E_INVALID, "srz_frameset_allgather: bad exchange kind");
+  if (c->world == 1) { // one rank: the shard is the frame
+    HIP_TRY(ctx, hipMemcpyAsync(d_full, d_shard, bytes, hipMemcpyDeviceToDevice, s));
+    return SRZ_OK;
+  }
+  const int rc = rccl().AllGather(d_shard, d_gathered, bytes, /* ncclUint8 */ 1, c->comm, s);
+  if (rc != 0) return fail(ctx, SRZ_E_NODEVICE, "ncclAllGather: " + rccl_err(rc));
+  return srz_frameset_deinterleave(ctx, fs, d_gathered, d_full, what, stream);
 }
 
 int srz_sync(srz_ctx *ctx) {

@@ -134,6 +134,8 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s);
+void launch_deinterleave(const void *gathered, void *full, uint32_t world, uint32_t n_fp, uint32_t bands_per_rank, uint32_t row_bytes,
+                         hipStream_t s);
 void launch_verify_fastmath(unsigned long long *d_out4, hipStream_t s);
 void launch_verify_fastdiv(unsigned long long *d_out3, hipStream_t s);
 void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s);

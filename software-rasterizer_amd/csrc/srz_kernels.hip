@@ -581,8 +581,7 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
       kd2 = (float)((texel >> 16) & 0xffu) * inv255;
     }
     c0 = c1 = c2 = 0.0f;
-#pragma unroll
-    for (uint32_t l = 0; l < n_lights; ++l) {
+    for (uint32_t l = 0; l < n_lights; ++l) { // (2 iterations known at compile time when L2P150: unrolled by the optimizer)
       float o0, o1, o2;
       v_blinn_phong<M, L2P150>(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
@@ -676,7 +675,6 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
       s_bump_common(m, sd, nx, ny, nz, u, v, K.kh, K.kn, snx, sny, snz, on);
       sx = px + (K.kn * nx) * on, sy = py + (K.kn * ny) * on, sz = pz + (K.kn * nz) * on;
     }
-#pragma unroll
     for (uint32_t l = 0; l < n_lights; ++l) {
       float o0, o1, o2;
       s_blinn_phong<M, L2P150>(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
@@ -1622,6 +1620,38 @@ void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint3
   if (!total) return;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(k_resolve8, dim3(grid), dim3(256), 0, s, planes, out, n_frames, rows, W, frame_stride);
+}
+
+// ================================================================================================================
+// k_deinterleave — the multi-GPU exchange's second half.  The all-gather leaves every rank's shard one after the other,
+//   gathered[rank][frame][plane][local band][32 rows][row bytes]        (band b = local band * world + rank),
+// and this kernel restores the reference's row-major planes,
+//   full[frame][plane][band][32 rows][row bytes],
+// in one pass of 16-byte (or 4-byte) units: consecutive threads copy consecutive units of one destination row.
+// ================================================================================================================
+template <typename U>
+__global__ __launch_bounds__(256) void k_deinterleave(const U *gathered, U *full, uint32_t world, uint32_t n_fp /* frames x planes */,
+                                                      uint32_t bands_per_rank, uint32_t row_units /* units per row */) {
+  const uint64_t band_units = (uint64_t)BAND * row_units, total = (uint64_t)n_fp * bands_per_rank * world * band_units;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t in_band = i % band_units, b = i / band_units; // b = (frame-plane, local band, rank) of the destination
+    const uint32_t rank = (uint32_t)(b % world), lb = (uint32_t)((b / world) % bands_per_rank);
+    const uint64_t fp = b / ((uint64_t)world * bands_per_rank);
+    full[i] = __builtin_nontemporal_load(gathered + (((uint64_t)rank * n_fp + fp) * bands_per_rank + lb) * band_units + in_band);
+  }
+}
+void launch_deinterleave(const void *gathered, void *full, uint32_t world, uint32_t n_fp, uint32_t bands_per_rank, uint32_t row_bytes,
+                         hipStream_t s) {
+  const bool wide = (row_bytes & 15u) == 0 && (((uintptr_t)gathered | (uintptr_t)full) & 15u) == 0;
+  const uint32_t unit = wide ? 16u : 4u, row_units = row_bytes / unit;
+  const uint64_t total = (uint64_t)n_fp * bands_per_rank * world * BAND * row_units;
+  if (!total) return;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
+  if (wide)
+    hipLaunchKernelGGL(k_deinterleave<u32x4>, dim3(grid), dim3(256), 0, s, (const u32x4 *)gathered, (u32x4 *)full, world, n_fp, bands_per_rank, row_units);
+  else
+    hipLaunchKernelGGL(k_deinterleave<uint32_t>, dim3(grid), dim3(256), 0, s, (const uint32_t *)gathered, (uint32_t *)full, world, n_fp, bands_per_rank,
+                       row_units);
 }
 
 // Exhaustive check of the short exact sequences above against the IEEE expansions: all 2^32 bit patterns.

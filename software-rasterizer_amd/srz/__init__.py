@@ -18,7 +18,9 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch"]
+           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch",
+           "srz_comm_unique_id", "srz_comm_create", "srz_comm_destroy", "srz_frameset_exchange_bytes", "srz_frameset_allgather",
+           "srz_frameset_deinterleave"]
 
 
 class SrzError(RuntimeError):
@@ -64,8 +66,24 @@ def lib():
         L.srz_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.srz_verify_fastmath.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_verify_fastdiv.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.srz_comm_unique_id.argtypes = [vp]
+        L.srz_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.srz_comm_destroy.argtypes = [vp, vp]
+        L.srz_comm_destroy.restype = None
+        L.srz_frameset_exchange_bytes.argtypes = [vp, vp, C.c_int]
+        L.srz_frameset_exchange_bytes.restype = C.c_size_t
+        L.srz_frameset_allgather.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
+        L.srz_frameset_deinterleave.argtypes = [vp, vp, vp, vp, C.c_int, vp]
         _lib = L
     return _lib
+
+
+def _stream(stream):
+    """hipStream_t argument of the C ABI: None → NULL = the ctx's own non-blocking stream; 0 (HIP's null stream, e.g. torch's
+    default stream) → SRZ_STREAM_NULL, because work on the ctx's stream is NOT ordered against the null stream."""
+    if stream is None:
+        return None
+    return C.c_void_p(-1 if stream == 0 else stream)
 
 
 def _fp(a):
@@ -95,13 +113,24 @@ class FrameSet:
 
     def render(self, d_out_ptr, out_bytes, flags=abi.FUSED_CLEAR, stream=None):
         """d_out_ptr: integer device address (e.g. torch_tensor.data_ptr()). Asynchronous."""
-        self.ctx._check(lib().srz_frameset_render(self.ctx.h, self.h, C.c_void_p(d_out_ptr), out_bytes, flags,
-                                                  C.c_void_p(stream) if stream else None))
+        self.ctx._check(lib().srz_frameset_render(self.ctx.h, self.h, C.c_void_p(d_out_ptr), out_bytes, flags, _stream(stream)))
 
     def resolve8(self, d_planes_ptr, d_bgr8_ptr, bgr8_bytes, stream=None):
         """display()'s 8-bit resolve on the device: planes (render output) → [frame][rows][W][3] uint8."""
         self.ctx._check(lib().srz_frameset_resolve8(self.ctx.h, self.h, C.c_void_p(d_planes_ptr), C.c_void_p(d_bgr8_ptr), bgr8_bytes,
-                                                    C.c_void_p(stream) if stream else None))
+                                                    _stream(stream)))
+
+    def exchange_bytes(self, what=abi.EXCHANGE_PLANES):
+        return int(lib().srz_frameset_exchange_bytes(self.ctx.h, self.h, what))
+
+    def allgather(self, comm, d_shard_ptr, d_gathered_ptr, d_full_ptr, what=abi.EXCHANGE_PLANES, stream=None):
+        """RCCL all-gather of this rank's shard + de-interleave into row-major frames (srz_frameset_allgather)."""
+        self.ctx._check(lib().srz_frameset_allgather(self.ctx.h, comm.h, self.h, C.c_void_p(d_shard_ptr), C.c_void_p(d_gathered_ptr),
+                                                     C.c_void_p(d_full_ptr), what, _stream(stream)))
+
+    def deinterleave(self, d_gathered_ptr, d_full_ptr, what=abi.EXCHANGE_PLANES, stream=None):
+        self.ctx._check(lib().srz_frameset_deinterleave(self.ctx.h, self.h, C.c_void_p(d_gathered_ptr), C.c_void_p(d_full_ptr), what,
+                                                        _stream(stream)))
 
     def stats(self):
         st = abi.SrzStats()
@@ -121,6 +150,29 @@ class FrameSet:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """RCCL communicator of the band exchange (srz_comm_*): rank 0 makes the id, the host program distributes it."""
+
+    def __init__(self, ctx, id128, rank, world):
+        self.ctx, self.h = ctx, C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        ctx._check(lib().srz_comm_create(ctx.h, buf, rank, world, C.byref(self.h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = lib().srz_comm_unique_id(buf)
+        if rc != 0:
+            raise SrzError(rc, lib().srz_last_error(None).decode())
+        return bytes(buf)
+
+    def close(self):
+        if self.h:
+            lib().srz_comm_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
 
 
 class Context:

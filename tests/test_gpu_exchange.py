@@ -1,0 +1,170 @@
+"""-m gpu: the multi-GPU exchange behind the C ABI (srz_comm_*, srz_frameset_allgather, srz_frameset_deinterleave).
+
+A single GPU can play every rank of an N-GPU job: each rank's band shard is rendered with its own sharded context, the
+all-gather's result (rank-major concatenation) is assembled by hand, and the HIP de-interleave pass must return the
+oracle's full frames bit for bit.  The RCCL communicator itself is exercised with world = 1 here and with world = 2 when
+two GPUs are visible."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from srz import abi, parallel
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("world,size", [(2, 256), (3, 320), (8, 512)])
+def test_deinterleave_kernel_restores_row_major_frames(orc, world, size):
+    import srz
+    frames = [scenes.config2(i, size=size) for i in (2, 11, 25)]
+    refs = [np.stack(orc.draw(f)[1]) for f in frames]
+    shards, shards8, fs_keep = [], [], []
+    for r in range(world):
+        ctx = srz.Context(0, r, world)
+        ctx.texture_upload(0, scenes.spot_texture())
+        fs = ctx.frameset(frames)
+        out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
+        b8 = torch.zeros((len(frames), 1, fs.local_rows, size * 3), dtype=torch.uint8, device="cuda")
+        fs.resolve8(out.data_ptr(), b8.data_ptr(), b8.numel(), s)
+        torch.cuda.synchronize()
+        shards.append(out), shards8.append(b8), fs_keep.append((ctx, fs))
+    ctx, fs = fs_keep[0]
+    bpr = fs.local_rows // 32
+    gathered = torch.stack(shards).contiguous()          # = what ncclAllGather leaves: [rank][frame][plane][rows][W]
+    full = torch.empty((len(frames), 4, bpr * world * 32, size), dtype=torch.float32, device="cuda")
+    fs.deinterleave(gathered.data_ptr(), full.data_ptr(), abi.EXCHANGE_PLANES, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = full.cpu().numpy()[:, :, :size]
+    for i in range(len(frames)):
+        assert np.array_equal(bits(got[i]), bits(refs[i])), i
+    assert torch.equal(full, parallel.deinterleave(gathered, world))                       # = the torch formulation
+    g8 = torch.stack(shards8).contiguous()
+    full8 = torch.empty((len(frames), 1, bpr * world * 32, size * 3), dtype=torch.uint8, device="cuda")
+    fs.deinterleave(g8.data_ptr(), full8.data_ptr(), abi.EXCHANGE_BGR8, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(len(frames)):
+        ref8 = orc.resolve8(tuple(refs[i]))
+        assert np.array_equal(full8[i, 0, :size].cpu().numpy().reshape(size, size, 3), ref8), i
+    for c, f in fs_keep:
+        f.close(), c.close()
+
+
+def test_communicator_of_one_rank(orc):
+    """srz_comm_unique_id / srz_comm_create / srz_frameset_allgather through librccl with world = 1"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    comm = srz.Comm(ctx, srz.Comm.unique_id(), 0, 1)
+    frames = [scenes.config2(i, size=256) for i in (1, 2)]
+    fs = ctx.frameset(frames)
+    assert fs.exchange_bytes(abi.EXCHANGE_PLANES) == fs.out_bytes and fs.exchange_bytes(abi.EXCHANGE_BGR8) == 2 * 256 * 256 * 3
+    out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+    gathered, full = torch.empty_like(out), torch.full_like(out, -7.0)
+    s = torch.cuda.Stream()
+    fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s.cuda_stream)
+    fs.allgather(comm, out.data_ptr(), gathered.data_ptr(), full.data_ptr(), abi.EXCHANGE_PLANES, s.cuda_stream)
+    s.synchronize()
+    for i, f in enumerate(frames):
+        ref = np.stack(orc.draw(f)[1])
+        assert np.array_equal(bits(full[i].cpu().numpy()), bits(ref))
+    with pytest.raises(srz.SrzError):   # a frameset of another shard
+        ctx2 = srz.Context(0, 1, 2)
+        fs2 = ctx2.frameset(frames)
+        fs2.allgather(comm, out.data_ptr(), gathered.data_ptr(), full.data_ptr())
+    comm.close()
+    ctx.close()
+
+
+def test_render_on_the_null_stream_is_ordered(orc):
+    """stream 0 (torch's default stream) must mean the NULL stream, not the context's private non-blocking stream: a torch
+    op queued right after the render has to see its result."""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    f = scenes.config2(4, size=512)
+    fs = ctx.frameset([f] * 8)
+    out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+    assert torch.cuda.current_stream().cuda_stream == 0
+    for _ in range(3):
+        out.fill_(-3.0)
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, 0)
+        copy = out.clone()          # torch's null stream: ordered after the render only if the render ran there
+    torch.cuda.synchronize()
+    ref = np.stack(orc.draw(f)[1])
+    assert np.array_equal(bits(copy[7].cpu().numpy()), bits(ref))
+    ctx.close()
+
+
+def _two_rank_worker(rank, world, port, q):
+    import conftest  # noqa: F401
+    import torch.distributed as dist
+    import srz
+    from oracle import oracle
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # (rendezvous only: the exchange is srz_comm's RCCL)
+    try:
+        oracle.texture_set(0, scenes.spot_texture())
+        ctx = srz.Context(rank, rank, world)
+        ctx.texture_upload(0, scenes.spot_texture())
+        ids = [srz.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = srz.Comm(ctx, ids[0], rank, world)
+        size, nf, steps = 256, 3, 5
+        sets = [ctx.frameset([scenes.config2(3 * k + i, size=size) for i in range(nf)]) for k in range(steps)]
+        fs0 = sets[0]
+        bpr = fs0.local_rows // 32
+        shard = [torch.zeros(fs0.out_shape, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.empty((world,) + tuple(fs0.out_shape), dtype=torch.float32, device="cuda") for _ in range(2)]
+        full = [torch.empty((nf, 4, bpr * world * 32, size), dtype=torch.float32, device="cuda") for _ in range(2)]
+        rq, xq = parallel.TorchQueue(), parallel.TorchQueue()
+        state = {"k": 0}
+        pipe = parallel.ExchangePipeline(
+            lambda b: sets[state["k"]].render(shard[b].data_ptr(), fs0.out_bytes, abi.FUSED_CLEAR, rq.handle),
+            lambda b: fs0.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), abi.EXCHANGE_PLANES, xq.handle),
+            rq, xq)
+        ok, snaps = True, []
+        for k in range(steps):   # a different set of frames every step: a torn or stale buffer cannot go unnoticed
+            state["k"] = k
+            b = pipe.step()
+            with torch.cuda.stream(xq.stream):
+                snaps.append(full[b].clone())
+        pipe.drain()
+        torch.cuda.synchronize()
+        for k in range(steps):
+            got = snaps[k].cpu().numpy()[:, :, :size]
+            for i in range(nf):
+                ref = np.stack(oracle.draw(scenes.config2(3 * k + i, size=size))[1])
+                ok = ok and np.array_equal(got[i].view(np.uint32), ref.view(np.uint32))
+        q.put((rank, ok))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_overlapped_exchange_equals_oracle():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    procs = [mctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res

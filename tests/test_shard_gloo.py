@@ -75,6 +75,71 @@ def test_band_sharding_allgather_reassembles_the_frame(world, height, width):
     assert all(r[1] for r in res), res
 
 
+def _pipeline_worker(rank, world, port, q):
+    """the overlapped render → exchange pipeline of bench.py (srz.parallel.ExchangePipeline) with two worker threads standing
+    in for the two HIP streams: different frames every step, every step's gathered frames checked before the buffer is reused"""
+    import conftest  # noqa: F401
+    import scenes
+    from oracle import oracle
+    from srz import parallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle.texture_set(scenes.TEX_SPOT, scenes.spot_texture())
+        size, nf, steps = 128, 2, 5
+        lay = parallel.shard_layout(size, rank, world)
+        shard = [torch.zeros((nf, 4, lay["local_rows"], size), dtype=torch.float32) for _ in range(2)]
+        gathered = [torch.empty((world,) + tuple(shard[0].shape), dtype=torch.float32) for _ in range(2)]
+        full = [torch.empty((nf, 4, lay["bands_per_rank"] * world * 32, size), dtype=torch.float32) for _ in range(2)]
+        bad = []
+
+        def render(b):
+            k = state_of[b]
+            for fi in range(nf):
+                f = scenes.config2(2 * k + fi, size=size)
+                planes = oracle.new_planes(size, size)
+                for (lb, band, r0, r1) in parallel.band_rows(size, rank, world):
+                    assert oracle.draw_rows(f, planes, r0, r1) == 0
+                    for p in range(4):
+                        shard[b][fi, p, lb * 32: lb * 32 + (r1 - r0)] = torch.from_numpy(planes[p][r0:r1])
+
+        def exchange(b):
+            parallel.all_gather_frames(shard[b], world, gathered[b], full[b])
+
+        def check(k, b):
+            for fi in range(nf):
+                ref = np.stack(oracle.draw(scenes.config2(2 * k + fi, size=size))[1])
+                if not np.array_equal(full[b][fi].numpy()[:, :size].view(np.uint32), ref.view(np.uint32)):
+                    bad.append((k, fi))
+
+        state_of = {}
+        rq, xq = parallel.ThreadQueue(), parallel.ThreadQueue()
+        pipe = parallel.ExchangePipeline(render, exchange, rq, xq)
+        for k in range(steps):
+            rq.submit(lambda k=k: state_of.__setitem__(k % 2, k))  # (on the render queue: in order with render(b))
+            b = pipe.step()
+            xq.submit(lambda k=k, b=b: check(k, b))
+        pipe.drain()
+        rq.close(), xq.close()
+        q.put((rank, not bad, bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_pipeline_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
 def test_shard_layout_matches_the_c_side_rules():
     from srz import parallel
     for h in (32, 33, 200, 1024, 1080, 4096):
