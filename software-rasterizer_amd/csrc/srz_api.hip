@@ -43,6 +43,11 @@ struct srz_ctx {
   uint64_t tex_version = 1;
   int acc_launches = 0;
   unsigned long long dbg[ST_COUNT] = {};
+  // srz_draw / srz_draw_scene keep their frameset and device framebuffer between calls: a call whose structure (size,
+  // batch sizes, shader types, light count) equals the previous one only re-uploads the data
+  srz_frameset *draw_fs = nullptr;
+  float *draw_out = nullptr;
+  std::vector<uint64_t> draw_sig;
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
   hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
@@ -64,6 +69,7 @@ struct srz_frameset {
   uint64_t total_tris = 0, total_lights = 0;
   std::vector<FrameDesc> h_frames;
   std::vector<BatchDesc> h_batches;
+  std::vector<ShadeDescG> h_sdesc;
   FrameDesc *d_frames = nullptr;
   srz_tri *d_tris = nullptr;
   BBox *d_bbox = nullptr;
@@ -264,7 +270,8 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       return fail(ctx, SRZ_E_TEXTURE, "batch uses texture slot " + std::to_string(b.tex_id) + " which was never uploaded");
   }
   if (fs->sdesc_version != ctx->tex_version && !fs->h_batches.empty()) { // (re)resolve batch → shader/texture
-    std::vector<ShadeDescG> h(fs->h_batches.size());
+    std::vector<ShadeDescG> &h = fs->h_sdesc; // (owned by the set: the asynchronous copy below may read it after we return)
+    h.resize(fs->h_batches.size());
     for (size_t i = 0; i < h.size(); ++i) {
       const BatchDesc &b = fs->h_batches[i];
       bool needs = b.shader == SRZ_SHADER_TEXTURE || b.shader == SRZ_SHADER_DISPLACEMENT || b.shader == SRZ_SHADER_BUMP;
@@ -272,7 +279,8 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       h[i].tw = needs ? ctx->h_tex[b.tex_id].w : 1, h[i].th = needs ? ctx->h_tex[b.tex_id].h : 1;
       h[i].tex = needs ? ctx->h_tex[b.tex_id].bgrx : nullptr;
     }
-    HIP_TRY(ctx, hipMemcpy(fs->d_sdesc, h.data(), sizeof(ShadeDescG) * h.size(), hipMemcpyHostToDevice));
+    // on the launch stream: ordered after the renders already submitted there, before this one
+    HIP_TRY(ctx, hipMemcpyAsync(fs->d_sdesc, h.data(), sizeof(ShadeDescG) * h.size(), hipMemcpyHostToDevice, s));
     fs->sdesc_version = ctx->tex_version;
   }
   // the record pool follows what the previous render asked for (read back asynchronously): growing is rare and the one
@@ -420,6 +428,8 @@ void srz_destroy(srz_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->draw_fs) srz_frameset_destroy(ctx, ctx->draw_fs);
+  (void)hipFree(ctx->draw_out);
   for (auto &ep : ctx->ev_used) ctx->ev_pool.push_back(ep);
   for (auto &ep : ctx->ev_pool) (void)hipEventDestroy(ep.t0), (void)hipEventDestroy(ep.t1), (void)hipEventDestroy(ep.t2), (void)hipEventDestroy(ep.t3);
   for (int i = 0; i < MAX_TEX; ++i) (void)hipFree(ctx->d_texmem[i]);
@@ -1129,6 +1139,26 @@ int srz_sync(srz_ctx *ctx) {
   return SRZ_OK;
 }
 
+// re-upload the data of a 1-frame set made by srz_frameset_create (same structure: checked by the caller's signature)
+static int refresh_plain_frame(srz_ctx *ctx, srz_frameset *fs, const srz_frame &fr, hipStream_t s) {
+  FrameDesc &d = fs->h_frames[0];
+  std::memcpy(d.eye, fr.eye, sizeof d.eye), std::memcpy(d.ka, fr.ka, sizeof d.ka), std::memcpy(d.ks, fr.ks, sizeof d.ks);
+  d.p = fr.p, d.kh = fr.kh, d.kn = fr.kn;
+  d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER);
+  classify_frames(fs);
+  HIP_TRY(ctx, hipMemcpyAsync(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc), hipMemcpyHostToDevice, s));
+  if (fr.n_lights) HIP_TRY(ctx, hipMemcpyAsync(fs->d_lights, fr.lights, sizeof(srz_light) * fr.n_lights, hipMemcpyHostToDevice, s));
+  size_t o = 0;
+  for (uint32_t b = 0; b < fr.n_batches; ++b) {
+    const srz_batch &sb = fr.batches[b];
+    if (sb.n_tris && !sb.tris) return fail(ctx, SRZ_E_INVALID, "srz_draw: batch with null triangle pointer");
+    if (sb.n_tris) HIP_TRY(ctx, hipMemcpyAsync(fs->d_tris + o, sb.tris, sizeof(srz_tri) * sb.n_tris, hipMemcpyHostToDevice, s));
+    o += sb.n_tris;
+  }
+  fs->have_stats = false;
+  return SRZ_OK;
+}
+
 static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const srz_scene_frame *scene, float *z, float *c0,
                      float *c1, float *c2, srz_stats *stats) {
   if (!ctx) return SRZ_E_INVALID;
@@ -1136,19 +1166,44 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
     return fail(ctx, SRZ_E_PRIMITIVE, "Primitive Type is not supported!");
   if ((!frame && !scene) || !z || !c0 || !c1 || !c2) return fail(ctx, SRZ_E_INVALID, "srz_draw: null argument");
   if (ctx->shard_world != 1) return fail(ctx, SRZ_E_INVALID, "srz_draw: whole-frame draw needs an unsharded ctx (srz_set_shard(ctx,0,1))");
-  srz_frameset *fs = nullptr;
-  int rc = frame ? srz_frameset_create(ctx, frame, 1, &fs) : srz_sceneset_create(ctx, scene, 1, &fs);
-  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
   const int W = frame ? frame->width : scene->width, H = frame ? frame->height : scene->height;
+  // ---- the structure of this call; equal to the previous call's → its frameset and framebuffer are reused ----------------
+  std::vector<uint64_t> sig;
+  if (frame) {
+    if ((frame->n_lights && !frame->lights) || (frame->n_batches && !frame->batches)) return fail(ctx, SRZ_E_INVALID, "srz_draw: null lights/batches");
+    sig = {1u, (uint64_t)(uint32_t)W << 32 | (uint32_t)H, frame->n_lights, frame->n_batches};
+    for (uint32_t b = 0; b < frame->n_batches; ++b)
+      sig.push_back((uint64_t)frame->batches[b].n_tris << 32 | (uint64_t)(uint8_t)frame->batches[b].shader << 16 | (uint16_t)frame->batches[b].tex_id);
+  } else {
+    sig = {2u, (uint64_t)(uint32_t)W << 32 | (uint32_t)H, scene->n_lights, scene->n_draws};
+  }
+  int rc = SRZ_OK;
+  bool reuse = ctx->draw_fs && sig == ctx->draw_sig;
+  if (reuse) {
+    rc = frame ? refresh_plain_frame(ctx, ctx->draw_fs, *frame, s) : srz_sceneset_update(ctx, ctx->draw_fs, scene, 1);
+    if (rc != SRZ_OK && !frame) reuse = false, rc = SRZ_OK; // (a scene whose mesh bindings changed: rebuild)
+    if (rc != SRZ_OK) return rc;
+  }
+  if (!reuse) {
+    if (ctx->draw_fs) srz_frameset_destroy(ctx, ctx->draw_fs);
+    (void)hipFree(ctx->draw_out);
+    ctx->draw_fs = nullptr, ctx->draw_out = nullptr, ctx->draw_sig.clear();
+    rc = frame ? srz_frameset_create(ctx, frame, 1, &ctx->draw_fs) : srz_sceneset_create(ctx, scene, 1, &ctx->draw_fs);
+    if (rc) return rc;
+    if (hipMalloc(&ctx->draw_out, 4 * (size_t)W * H * sizeof(float)) != hipSuccess) {
+      srz_frameset_destroy(ctx, ctx->draw_fs);
+      ctx->draw_fs = nullptr;
+      return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc failed");
+    }
+    ctx->draw_sig = sig;
+  }
+  srz_frameset *fs = ctx->draw_fs;
+  float *d_out = ctx->draw_out;
   const uint32_t fflags = frame ? frame->flags : scene->flags;
   const size_t plane = (size_t)W * H, pb = plane * sizeof(float);
-  float *d_out = nullptr;
-  hipError_t e = hipMalloc(&d_out, 4 * pb);
-  if (e != hipSuccess) {
-    srz_frameset_destroy(ctx, fs);
-    return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc failed");
-  }
-  hipStream_t s = ctx->stream;
+  hipError_t e = hipSuccess;
   const bool fused = (fflags & SRZ_FUSED_CLEAR) != 0;
   float *host[4] = {z, c0, c1, c2};
   if (!fused)
@@ -1160,8 +1215,6 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
   for (int p = 0; p < 4 && e == hipSuccess && rc == SRZ_OK; ++p)
     e = hipMemcpyAsync(host[p], d_out + p * plane, pb, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(d_out);
-  srz_frameset_destroy(ctx, fs);
   if (e != hipSuccess) return fail(ctx, SRZ_E_NODEVICE, std::string("srz_draw: ") + hipGetErrorString(e));
   return rc;
 }

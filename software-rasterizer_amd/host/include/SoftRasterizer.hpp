@@ -236,6 +236,7 @@ public:
   const std::vector<uint8_t> &frameBuffer8() const { return m_frameBuffer8; } // interleaved 3 x u8 after display()
 
   virtual void draw(Primitive type) = 0; // protected in the reference; public here so harnesses can time draw() alone
+  void finish();                          // waits for the device to finish what draw() submitted (draw() is asynchronous)
 
 protected:
   void clearFrameBuffer();
@@ -273,7 +274,12 @@ private:
   void init();
   std::unordered_map<const Scene *, srz_frameset *> m_sceneSets; // cached 1-frame scenesets (device vertex stage)
   std::unordered_map<const TextureLoader *, int> m_texSlots;
-  std::unordered_map<const Object *, std::pair<int, std::size_t>> m_meshSlots; // mesh → (slot, face count at upload)
+  struct MeshSlot {
+    int slot;
+    std::size_t n_faces;
+    std::uint64_t hash; // of the vertices and faces as uploaded
+  };
+  std::unordered_map<const Object *, MeshSlot> m_meshSlots; // mesh → its copy on the GPU
   int textureSlot(const std::shared_ptr<Shader> &sh);
   std::vector<std::weak_ptr<TextureLoader>> m_texOwners;
 };

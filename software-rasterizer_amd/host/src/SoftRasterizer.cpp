@@ -544,6 +544,10 @@ int TraditionalRasterizer::textureSlot(const std::shared_ptr<Shader> &sh) {
   return it->second;
 }
 
+void RenderingPipeline::finish() {
+  if (m_ctx && srz_sync(m_ctx) != SRZ_OK) throw std::runtime_error(std::string("finish: ") + srz_last_error(m_ctx));
+}
+
 void TraditionalRasterizer::draw(Primitive type) {
   if ((type != Primitive::LINES) && (type != Primitive::TRIANGLES)) {
     log("error", "Primitive Type is not supported!");
@@ -566,11 +570,26 @@ void TraditionalRasterizer::draw(Primitive type) {
         const auto &faces = md.mesh->getFaces();
         if (faces.empty()) continue;
         if (!md.shader) throw std::runtime_error("draw: a mesh with triangles has no shader bound (bindShader2Mesh)"); // D14
+        // The GPU copy of a mesh is reused only while the mesh is PROVEN unchanged: the reference re-reads vertices and
+        // faces on every draw() (src/Scene.cpp:927-947) and both are public members, so a content hash (≈25 µs for spot)
+        // is the only proof there is — an in-place edit, or a new mesh at a recycled address, re-uploads.
+        const auto &V = md.mesh->getVertices();
+        auto hash_bytes = [](const void *p, size_t n, uint64_t h) {
+          const unsigned char *b = static_cast<const unsigned char *>(p);
+          for (; n >= 8; n -= 8, b += 8) {
+            uint64_t w;
+            std::memcpy(&w, b, 8);
+            h = (h ^ w) * 0x9E3779B97F4A7C15ull, h ^= h >> 29;
+          }
+          for (; n; --n, ++b) h = (h ^ *b) * 0x100000001B3ull;
+          return h;
+        };
+        uint64_t hash = hash_bytes(V.data(), V.size() * sizeof(V[0]), 0xcbf29ce484222325ull ^ V.size());
+        hash = hash_bytes(faces.data(), faces.size() * sizeof(faces[0]), hash ^ (faces.size() << 1));
         auto it = m_meshSlots.find(md.mesh);
-        if (it == m_meshSlots.end() || it->second.second != faces.size()) {
-          const int slot = it == m_meshSlots.end() ? (int)m_meshSlots.size() : it->second.first;
+        if (it == m_meshSlots.end() || it->second.hash != hash || it->second.n_faces != faces.size()) {
+          const int slot = it == m_meshSlots.end() ? (int)m_meshSlots.size() : it->second.slot;
           if (slot >= 256) throw std::runtime_error("draw: more than 256 meshes");
-          const auto &V = md.mesh->getVertices();
           std::vector<srz_vertex> v(V.size());
           for (size_t i = 0; i < V.size(); ++i) {
             v[i].pos[0] = V[i].position.x, v[i].pos[1] = V[i].position.y, v[i].pos[2] = V[i].position.z;
@@ -581,11 +600,11 @@ void TraditionalRasterizer::draw(Primitive type) {
           for (size_t i = 0; i < faces.size(); ++i) f[3 * i] = faces[i].x, f[3 * i + 1] = faces[i].y, f[3 * i + 2] = faces[i].z;
           int rc = srz_mesh_upload(m_ctx, slot, v.data(), (uint32_t)v.size(), f.data(), (uint32_t)faces.size());
           if (rc != SRZ_OK) throw std::runtime_error(std::string("draw: ") + srz_last_error(m_ctx));
-          m_meshSlots[md.mesh] = {slot, faces.size()};
+          m_meshSlots[md.mesh] = MeshSlot{slot, faces.size(), hash};
           it = m_meshSlots.find(md.mesh);
         }
         srz_mesh_draw d{};
-        d.mesh_id = it->second.first, d.shader = (int)md.shader->type(), d.tex_id = -1;
+        d.mesh_id = it->second.slot, d.shader = (int)md.shader->type(), d.tex_id = -1;
         const SHADERS_TYPE st = md.shader->type();
         if (st == SHADERS_TYPE::TEXTURE || st == SHADERS_TYPE::DISPLACEMENT || st == SHADERS_TYPE::BUMP) d.tex_id = textureSlot(md.shader);
         std::memcpy(d.ndc_mvp, md.ndc_mvp.data(), 64), std::memcpy(d.normal_m, md.normal_m.data(), 64);

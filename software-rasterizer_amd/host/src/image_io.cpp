@@ -59,8 +59,12 @@ static void decode_png(const std::vector<uint8_t> &d, const std::string &path, s
   if (!have_hdr || W <= 0 || H <= 0 || idat.empty()) throw std::runtime_error("Cannot open file: " + path);
   if (interlace) throw std::runtime_error("Cannot open file (interlaced PNG not supported): " + path);
   int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-  if (!channels || (depth != 8 && depth != 16 && !((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
-    throw std::runtime_error("Cannot open file (unsupported PNG layout): " + path);
+  // the layouts of the PNG specification: grey 1/2/4/8/16, palette 1/2/4/8 (never 16), truecolour / with alpha 8/16
+  const bool depth_ok = ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                   : (depth == 8 || depth == 16 || (ctype == 0 && (depth == 1 || depth == 2 || depth == 4)));
+  if (!channels || !depth_ok) throw std::runtime_error("Cannot open file (unsupported PNG layout): " + path);
+  if (W > 32768 || H > 32768) // (what srz_texture_upload accepts; also bounds the allocations below for a malformed header)
+    throw std::runtime_error("Cannot open file (image larger than 32768 x 32768): " + path);
   const size_t bpp_bits = (size_t)channels * depth, stride = ((size_t)W * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
   std::vector<uint8_t> raw((stride + 1) * (size_t)H);
   uLongf out_len = (uLongf)raw.size();

@@ -13,6 +13,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SPOT_OBJ = os.path.join(REPO, "assets/models/spot/spot_triangulated_good.obj")
 SPOT_TEX = os.path.join(REPO, "assets/models/spot/spot_texture.png")
 BUNNY_OBJ = os.path.join(REPO, "assets/models/bunny/bunny.obj")
+CRATE_OBJ = os.path.join(REPO, "assets/models/Crate/Crate1.obj")
+CRATE_TEX = os.path.join(REPO, "assets/models/Crate/Crate1.png")
 
 EYE = (0.0, 0.0, 0.9)
 L1 = ((0.9, 0.9, -0.9), (100, 100, 100))
@@ -23,17 +25,19 @@ Y = (0, 1, 0)
 class Workload:
     """A host Scene plus the per-frame model-matrix recipe; frame(i) returns an abi.Frame (post-MVP stream)."""
 
-    def __init__(self, name, width, height, meshes):
-        """meshes: list of (mesh_name, obj_path, shader_type, translation, scale)."""
-        self.name, self.width, self.height, self.meshes = name, width, height, meshes
-        sc = host.Scene(name, EYE, (0, 0, 0), Y, width, height)
+    def __init__(self, name, width, height, meshes, eye=EYE):
+        """meshes: list of (mesh_name, obj_path, shader_type, translation, scale[, texture_path])."""
+        meshes = [tuple(m) + ((SPOT_TEX,) if len(m) == 5 else ()) for m in meshes]
+        self.name, self.width, self.height, self.eye = name, width, height, eye
+        self.meshes = [m[:5] for m in meshes]
+        sc = host.Scene(name, eye, (0, 0, 0), Y, width, height)
         textured = {}
-        for (mname, path, shader, t, s) in meshes:
+        for (mname, path, shader, t, s, tex) in meshes:
             sc.add_obj(path, mname, Y, 0.0, t, (s, s, s))
-            sname = f"shader{int(shader)}"
+            sname = f"shader{int(shader)}_{os.path.basename(tex)}"
             if sname not in textured:
                 # every Shader needs a loadable image in the reference, NORMAL / PHONG included (src/Scene.cpp:158)
-                sc.add_shader(sname, SPOT_TEX, shader)
+                sc.add_shader(sname, tex, shader)
                 textured[sname] = True
             sc.bind(mname, sname)
         sc.add_light("Light1", *L1)
@@ -41,6 +45,7 @@ class Workload:
         self.scene = sc
         self.textures = {}  # id(ndarray) -> slot
         self.texture_arrays = []
+        self.mesh_tex_slot = {}  # mesh name -> texture slot (scene_frame)
 
     def _slot(self, tex):
         if tex is None:
@@ -56,12 +61,14 @@ class Workload:
         sc = self.scene
         for (mname, _, _, t, s) in self.meshes:
             sc.set_model(mname, Y, deg, t, (s, s, s))
-        sc.set_view(EYE, (0, 0, 0), Y)
+        sc.set_view(self.eye, (0, 0, 0), Y)
         sc.set_projection(45.0, 0.1, 100.0)  # raw 45 into a radians API, as the reference does (src/main.cpp:156-159)
         batches = []
-        for (shader, tex, tris) in sc.stream():
+        for (mesh, (shader, tex, tris)) in zip(self.meshes, sc.stream()):
             needs = shader in (abi.SHADER_TEXTURE, abi.SHADER_DISPLACEMENT, abi.SHADER_BUMP)
             batches.append((shader, self._slot(tex) if needs else -1, tris))
+            if needs:
+                self.mesh_tex_slot[mesh[0]] = batches[-1][1]
         ka, ks, p, kh, kn = host.shader_constants()
         return abi.Frame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), batches, flags, ka, ks, p, kh, kn)
 
@@ -77,7 +84,7 @@ class Workload:
         sc = self.scene
         for (mname, _, _, t, s) in self.meshes:
             sc.set_model(mname, Y, deg, t, (s, s, s))
-        sc.set_view(EYE, (0, 0, 0), Y)
+        sc.set_view(self.eye, (0, 0, 0), Y)
         sc.set_projection(45.0, 0.1, 100.0)
         if not self.texture_arrays:
             self.frame(frame_idx)  # registers the texture slots
@@ -86,7 +93,7 @@ class Workload:
         d = []
         for (name, shader, mvp, nm) in draws:
             needs = shader in (abi.SHADER_TEXTURE, abi.SHADER_DISPLACEMENT, abi.SHADER_BUMP)
-            d.append((slot[name], shader, 0 if needs else -1, mvp, nm))
+            d.append((slot[name], shader, self.mesh_tex_slot.get(name, 0) if needs else -1, mvp, nm))
         ka, ks, p, kh, kn = host.shader_constants()
         return abi.SceneFrame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), d, zs, zo, flags, ka, ks, p, kh, kn)
 
@@ -121,5 +128,14 @@ def spot_overdraw8_4096():
     return Workload("spot_x8_overdraw_4096", 4096, 4096, meshes)
 
 
-WORKLOADS = {"spot_texture_1024": spot_texture_1024, "spot_bunny_phong_1080p": spot_bunny_1080p,
+def readme_spot_crate_1024():
+    """The scene of the reference's only published raster number (README.md:619-642, src/main.cpp:78-132): 1024x1024, spot
+    (5856 triangles) + Crate1.obj (6 quads → 12 triangles), both TEXTURE with their own images, eye (0,0,-0.9); the three
+    spheres of that scene contribute no raster triangles.  Lights: the README's two (README.md:189-194)."""
+    return Workload("readme_spot_crate_1024", 1024, 1024,
+                    [("spot", SPOT_OBJ, abi.SHADER_TEXTURE, (0.28, 0.1, 0.20), 0.2, SPOT_TEX),
+                     ("Crate", CRATE_OBJ, abi.SHADER_TEXTURE, (0.28, -0.13, 0.15), 0.1, CRATE_TEX)], eye=(0.0, 0.0, -0.9))
+
+
+WORKLOADS = {"readme_spot_crate_1024": readme_spot_crate_1024, "spot_texture_1024": spot_texture_1024, "spot_bunny_phong_1080p": spot_bunny_1080p,
              "spot_x16_texture_2048": spot_grid16_2048, "spot_x8_overdraw_4096": spot_overdraw8_4096}

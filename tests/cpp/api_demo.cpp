@@ -88,6 +88,25 @@ int main(int argc, char **argv) {
       for (int c = 0; c < 3; ++c) std::fwrite(render->channel(c).data(), 4, 256 * 256, fp);
       std::fclose(fp);
     }
+    { // the reference re-reads the mesh on every draw() (src/Scene.cpp:927-947): an in-place edit of the vertices (same face
+      // count, same object) must reach the GPU copy the device vertex stage keeps
+      auto obj = scene->getMeshObj("spot");
+      auto *mesh = obj ? dynamic_cast<SoftRasterizer::Mesh *>(obj->get()) : nullptr;
+      if (!mesh) return 1;
+      for (auto &v : mesh->vertices) v.position = v.position * 0.5f;
+      for (auto r : {render, render2}) {
+        r->clear(SoftRasterizer::Buffers::Color | SoftRasterizer::Buffers::Depth);
+        scene->setProjectionMatrix(45.0f, 0.1f, 100.0f);
+        r->draw(SoftRasterizer::Primitive::TRIANGLES);
+      }
+      size_t cov2 = 0;
+      for (float z : render->zBuffer()) cov2 += std::isfinite(z) ? 1 : 0;
+      std::printf("after the in-place edit: covered=%zu\n", cov2);
+      if (cov2 == 0 || cov2 * 3 > covered * 2) return 1; // half the size: about a quarter of the pixels
+      if (std::memcmp(render2->zBuffer().data(), render->zBuffer().data(), 256 * 256 * 4) != 0) return 1;
+      for (int c = 0; c < 3; ++c)
+        if (std::memcmp(render2->channel(c).data(), render->channel(c).data(), 256 * 256 * 4) != 0) return 1;
+    }
     bool threw = false;
     try {
       render->draw(static_cast<SoftRasterizer::Primitive>(7));

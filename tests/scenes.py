@@ -17,11 +17,13 @@ from srz import abi  # noqa: E402
 SPOT_OBJ = os.path.join(REPO, "assets/models/spot/spot_triangulated_good.obj")
 SPOT_TEX = os.path.join(REPO, "assets/models/spot/spot_texture.png")
 BUNNY_OBJ = os.path.join(REPO, "assets/models/bunny/bunny.obj")
+CRATE_OBJ = os.path.join(REPO, "assets/models/Crate/Crate1.obj")
+CRATE_TEX = os.path.join(REPO, "assets/models/Crate/Crate1.png")
 
 # README.md:189-194
 LIGHTS = np.array([[[0.9, 0.9, -0.9], [100, 100, 100]], [[0.0, 0.8, 0.9], [50, 50, 50]]], np.float32)
 EYE = (0.0, 0.0, 0.9)
-TEX_SPOT = 0
+TEX_SPOT, TEX_CRATE = 0, 1
 
 
 @functools.lru_cache(maxsize=None)
@@ -33,6 +35,11 @@ def mesh(path):
 @functools.lru_cache(maxsize=None)
 def spot_texture():
     return objload.load_texture_bgr(SPOT_TEX)
+
+
+@functools.lru_cache(maxsize=None)
+def crate_texture():
+    return objload.load_texture_bgr(CRATE_TEX)
 
 
 def camera(width, height, eye=EYE):
@@ -95,3 +102,15 @@ def config5(frame_idx=0, size=4096, flags=abi.FUSED_CLEAR):
         sh = abi.SHADER_NORMAL if k % 2 == 0 else abi.SHADER_PHONG
         batches.append((sh, -1, mesh_stream(SPOT_OBJ, size, size, deg, (0, 0, 0.05 * k), 0.3)))
     return abi.Frame(size, size, EYE, LIGHTS, batches, flags)
+
+
+README_EYE = (0.0, 0.0, -0.9)
+
+
+def readme_scene(frame_idx=0, size=1024, flags=abi.FUSED_CLEAR):
+    """The scene behind the reference's published raster timing (README.md:619-642; placement src/main.cpp:119-132, eye :150):
+    spot + Crate1.obj (6 quads, fan-triangulated to 12 triangles), both TEXTURE with their own images, 1024x1024."""
+    deg = float((10 * frame_idx) % 360)
+    spot = mesh_stream(SPOT_OBJ, size, size, deg, (0.28, 0.1, 0.20), 0.2, README_EYE)
+    crate = mesh_stream(CRATE_OBJ, size, size, deg, (0.28, -0.13, 0.15), 0.1, README_EYE)
+    return abi.Frame(size, size, README_EYE, LIGHTS, [(abi.SHADER_TEXTURE, TEX_SPOT, spot), (abi.SHADER_TEXTURE, TEX_CRATE, crate)], flags)

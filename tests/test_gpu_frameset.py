@@ -228,3 +228,43 @@ def test_draw_batch_host_buffers_equal_per_frame_draw(orc):
     with pytest.raises(srz.SrzError):
         ctx.draw_batch(fr, planes, primitive=7)
     ctx.close()
+
+
+def test_undocumented_flag_bits_and_debug_environment_are_ignored(orc, frames, monkeypatch):
+    """the kernel-ablation switches of the development builds are gone: neither SRZ_DEBUG_FLAGS nor stray high flag bits
+    change a render"""
+    import srz
+    monkeypatch.setenv("SRZ_DEBUG_FLAGS", "1")
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    _, a = render(ctx, frames)
+    _, b = render(ctx, frames, flags=abi.FUSED_CLEAR | 0xff00)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    rc, ref, _ = orc.draw(frames[2])
+    assert np.array_equal(bits(a[2].cpu().numpy()), bits(np.stack(ref)))
+    ctx.close()
+
+
+def test_srz_draw_reuses_its_frameset_between_calls(orc):
+    """srz_draw keeps its device state while the structure of the calls is unchanged and re-uploads only the data; a change
+    of structure (another size, another batch layout) rebuilds it.  Every call must equal the oracle."""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    seq = [scenes.config2(1, size=256), scenes.config2(9, size=256), scenes.config2(9, size=256, shader=abi.SHADER_PHONG),
+           scenes.config2(4, size=320), scenes.config2(5, size=320), scenes.config3(2, 320, 200), scenes.config2(6, size=256)]
+    for i, f in enumerate(seq):
+        rc, ref, rst = orc.draw(f)
+        gpu, gst = ctx.draw(f, want_stats=(i % 2 == 0))
+        for p in range(4):
+            assert np.array_equal(bits(gpu[p]), bits(ref[p])), (i, p)
+        assert gst is None or gst == rst
+    # accumulate mode through the cached path: the second draw starts from the first one's planes
+    f0, f1 = scenes.config2(0, size=256), scenes.config2(18, size=256, flags=0)
+    rc, ref, _ = orc.draw(f0)
+    rc, ref, _ = orc.draw(f1, ref)
+    gpu, _ = ctx.draw(f0)
+    gpu, _ = ctx.draw(f1, gpu)
+    for p in range(4):
+        assert np.array_equal(bits(gpu[p]), bits(ref[p])), p
+    ctx.close()

@@ -96,6 +96,21 @@ def test_config5_overdraw_4096(ctx, orc):
 
 
 # ------------------------------------------------------------------------------------------------ flags / accumulation
+@pytest.mark.parametrize("frame_idx", [0, 5, 21])
+def test_readme_scene_spot_and_crate(ctx, orc, frame_idx):
+    """the scene of the reference's published raster timing (README.md:619-642): spot + Crate1.obj, two textures"""
+    orc.texture_set(scenes.TEX_CRATE, scenes.crate_texture())
+    ctx.texture_upload(scenes.TEX_CRATE, scenes.crate_texture())
+    gpu, ref = run_both(ctx, orc, scenes.readme_scene(frame_idx))
+    compare(gpu, ref, f"readme scene frame={frame_idx}")
+    assert (orc.resolve8(gpu) == orc.resolve8(ref)).all()
+    f = scenes.readme_scene(frame_idx)
+    rc, spot_only, _ = orc.draw(abi.Frame(f.width, f.height, scenes.README_EYE, scenes.LIGHTS, [(abi.SHADER_TEXTURE, scenes.TEX_SPOT, f.tris[0])],
+                                          abi.FUSED_CLEAR))
+    crate_px = int(np.isfinite(ref[0]).sum() - np.isfinite(spot_only[0]).sum())
+    assert crate_px > 2000, crate_px                        # the 12 crate triangles do cover their share of the frame
+
+
 def test_unified_flag(ctx, orc):
     gpu, ref = run_both(ctx, orc, scenes.config2(5, size=512, flags=abi.FUSED_CLEAR | abi.UNIFIED))
     compare(gpu, ref, "unified")

@@ -40,6 +40,25 @@ def test_png_decoder_variants(tmp_path):
         host.load_image_bgr(str(tmp_path / "missing.png"))
 
 
+def test_png_decoder_rejects_malformed_headers(tmp_path):
+    """a palette image that claims 16 bits per sample (no such PNG layout: it used to divide by zero) and absurd sizes must
+    raise the loader's error, not crash the host process"""
+    import struct
+    import zlib
+
+    def png(w, h, depth, ctype, payload=b"\0" * 64):
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) +
+                chunk(b"PLTE", bytes(range(48))) + chunk(b"IDAT", zlib.compress(payload)) + chunk(b"IEND", b""))
+    for name, data in {"pal16": png(4, 4, 16, 3), "huge": png(1 << 30, 1 << 30, 8, 2), "rgb4": png(4, 4, 4, 2),
+                       "toolarge": png(40000, 2, 8, 0)}.items():
+        p = tmp_path / f"{name}.png"
+        p.write_bytes(data)
+        with pytest.raises(RuntimeError):
+            host.load_image_bgr(str(p))
+
+
 @pytest.mark.parametrize("path", [pscenes.SPOT_OBJ, pscenes.BUNNY_OBJ])
 def test_obj_loader_matches_the_restatement(path):
     v_ref, f_ref = oscenes.mesh(path)
@@ -95,6 +114,41 @@ def test_vertex_stage_matches_the_oracle_config3_and_4():
         for a, b in zip(f.tris, fo.tris):
             assert np.array_equal(bits(a), bits(b))
         assert [int(b.shader) for b in f._batches[:len(f.tris)]] == [int(b.shader) for b in fo._batches[:len(fo.tris)]]
+
+
+def test_readme_scene_spot_and_crate_matches_the_oracle_side():
+    """the README benchmark scene through the C++ ObjLoader (Crate1.obj: quads, fan triangulation, v → 1 - v) and PNG decoder
+    vs the oracle-side restatement, bit for bit; and facts any OBJ reader must agree on, taken from the files themselves"""
+    wl = pscenes.readme_spot_crate_1024()
+    for i in (0, 9):
+        f, fo = wl.frame(i), oscenes.readme_scene(i)
+        assert [len(t) for t in f.tris] == [5856, 12]
+        for a, b in zip(f.tris, fo.tris):
+            assert np.array_equal(bits(a), bits(b))
+        assert tuple(f.c.eye) == tuple(fo.c.eye) and f.c.eye[2] < 0
+    assert np.array_equal(wl.texture_arrays[0], oscenes.spot_texture()) and np.array_equal(wl.texture_arrays[1], oscenes.crate_texture())
+    from PIL import Image
+    assert np.array_equal(wl.texture_arrays[1], np.asarray(Image.open(pscenes.CRATE_TEX).convert("RGB"), np.uint8)[:, :, ::-1])
+    # independent of every loader in this repository: a line-level reading of the file
+    for path, mesh_name in ((pscenes.CRATE_OBJ, "Crate"), (pscenes.SPOT_OBJ, "spot")):
+        pos, polys = [], []
+        for line in open(path):
+            w = line.split()
+            if w[:1] == ["v"]:
+                pos.append([float(x) for x in w[1:4]])
+            elif w[:1] == ["f"]:
+                polys.append([int(t.split("/")[0]) - 1 for t in w[1:]])
+        pos = np.asarray(pos, np.float32)
+        v, faces = wl.scene.mesh(mesh_name)                         # (nV, 8) pos3 nrm3 uv2 ; (nF, 3)
+        assert len(faces) == sum(len(p) - 2 for p in polys)         # an n-gon makes n - 2 triangles
+        file_pos = {tuple(p) for p in pos.tolist()}
+        assert {tuple(p) for p in v[:, :3].tolist()} <= file_pos    # no invented positions
+        k = 0
+        for p in polys:                                             # fan order: (p0, p_i, p_i+1)
+            for i in range(1, len(p) - 1):
+                tri = v[faces[k], :3]
+                assert np.array_equal(tri, pos[[p[0], p[i], p[i + 1]]]), (mesh_name, k)
+                k += 1
 
 
 def test_scene_error_conventions(tmp_path, capfd):
