@@ -1324,6 +1324,9 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 }
 
 // k_shade is latency-sensitive: measurably slower at 3 waves per SIMD than at 4 — hold the allocator to 128 VGPRs
+#ifndef SRZ_FAST_MINW
+#define SRZ_FAST_MINW 5
+#endif
 #ifndef SRZ_SHADE_MINW
 #define SRZ_SHADE_MINW 4
 #endif
@@ -1335,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 //   generic  every other frame with per-pixel generality (any shader, any light count, any exponent), FastMath first and
 //            the IEEE expansions for a tile that needs them; then the tiles the FAST build handed back, IEEE at once.
 template <bool STATS, bool FAST>
-__global__ __launch_bounds__(256, FAST ? 5 : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
+__global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];
@@ -1357,12 +1360,6 @@ __global__ __launch_bounds__(256, FAST ? 5 : SRZ_SHADE_MINW) void k_shade(Render
     const uint32_t tri_off = fd->tri_off, batch_off = fd->batch_off;
     const uint32_t flags = fd->flags | a.flags_or;
     const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
-    FrameK K;
-    K.eye[0] = fd->eye[0], K.eye[1] = fd->eye[1], K.eye[2] = fd->eye[2];
-    K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
-    K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
-    K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
-    K.lights = as_const(a.lights) + fd->light_off;
     const SRZ_CAS srz_tri *tris = as_const(a.tris) + tri_off;
     const SRZ_CAS uint16_t *tri_batch = as_const(a.tri_batch) + tri_off;
     const SRZ_CAS ShadeDescG *sdesc = as_const(a.sdesc) + batch_off;
@@ -1407,18 +1404,15 @@ __global__ __launch_bounds__(256, FAST ? 5 : SRZ_SHADE_MINW) void k_shade(Render
     *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
     *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
-    // classify this thread's 4 pixels; per-wave class counts go through LDS (no atomics: a wave's first slot in each list
-    // is the sum of the counts of the waves before it)
-    unsigned long long mv[4], ms[4];
-    uint32_t cv = 0, cs = 0;
+    // classify this thread's 4 pixels and compact them BY CLASS into the two lists (V from the front, S from the back):
+    // per-thread counts, one packed wave scan (DPP), the waves' totals through LDS — no atomics, and the lists come out in
+    // row-major pixel order
+    const uint32_t idk[4] = {id4.x, id4.y, id4.z, id4.w};
+    uint32_t cnt2 = 0; // V count | S count << 16 of this thread
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t id = k == 0 ? id4.x : k == 1 ? id4.y : k == 2 ? id4.z : id4.w;
-      const bool own = id != NO_TRI, isS = own && (id & S_CLASS_BIT) != 0;
-      mv[k] = __ballot(own && !isS), ms[k] = __ballot(isS);
-      cv += (uint32_t)__popcll(mv[k]), cs += (uint32_t)__popcll(ms[k]);
-    }
-    if (lane == 0) s_wcnt[wave][0] = cv, s_wcnt[wave][1] = cs;
+    for (int k = 0; k < 4; ++k) cnt2 += idk[k] == NO_TRI ? 0u : ((idk[k] & S_CLASS_BIT) ? 0x10000u : 1u);
+    const uint32_t incl2 = wave_scan_add(cnt2);
+    if (lane == 63) s_wcnt[wave][0] = incl2 & 0xffffu, s_wcnt[wave][1] = incl2 >> 16;
     if (tid == 0) s_flag = 0;
     __syncthreads();
     uint32_t bV = 0, bS = 0, nV = 0, nS = 0; // this wave's first slot in each list, list lengths (all wave-uniform)
@@ -1427,15 +1421,14 @@ __global__ __launch_bounds__(256, FAST ? 5 : SRZ_SHADE_MINW) void k_shade(Render
       const uint32_t v = s_wcnt[w2][0], sN = s_wcnt[w2][1];
       bV += w2 < wave ? v : 0u, bS += w2 < wave ? sN : 0u, nV += v, nS += sN;
     }
-    bV = (uint32_t)__builtin_amdgcn_readfirstlane((int)bV), bS = (uint32_t)__builtin_amdgcn_readfirstlane((int)bS);
     nV = (uint32_t)__builtin_amdgcn_readfirstlane((int)nV), nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)nS);
     {
-      const unsigned long long lt = (1ull << lane) - 1ull;
+      uint32_t oV = bV + ((incl2 - cnt2) & 0xffffu), oS = TILE * TILE - 1 - (bS + ((incl2 - cnt2) >> 16));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if ((mv[k] >> lane) & 1ull) s_list[bV + __popcll(mv[k] & lt)] = (uint16_t)(p0 + k);
-        if ((ms[k] >> lane) & 1ull) s_list[TILE * TILE - 1 - (bS + __popcll(ms[k] & lt))] = (uint16_t)(p0 + k);
-        bV += (uint32_t)__popcll(mv[k]), bS += (uint32_t)__popcll(ms[k]);
+        const bool own = idk[k] != NO_TRI, isS = own && (idk[k] & S_CLASS_BIT) != 0;
+        if (own) s_list[isS ? oS : oV] = (uint16_t)(p0 + k);
+        oV += (own && !isS) ? 1u : 0u, oS -= isS ? 1u : 0u;
       }
     }
     __syncthreads();
@@ -1448,6 +1441,14 @@ __global__ __launch_bounds__(256, FAST ? 5 : SRZ_SHADE_MINW) void k_shade(Render
       using M = decltype(policy);
       constexpr bool isV = decltype(is_v)::value;
       bool bad = false;
+      // the frame's shading constants are (re)read here, after the IO phase: scalar loads from a hot line, and ~20 SGPRs
+      // fewer alive across the phase that has none to spare
+      FrameK K;
+      K.eye[0] = fd->eye[0], K.eye[1] = fd->eye[1], K.eye[2] = fd->eye[2];
+      K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
+      K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
+      K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
+      K.lights = as_const(a.lights) + fd->light_off;
       for (uint32_t c = (uint32_t)wave; c < cV + cS; c += 4) { // chunk c of the tile: V chunks first, then S chunks
         if ((c < cV) != isV) continue;
         const uint32_t i = (isV ? c : c - cV) * 64 + lane;
