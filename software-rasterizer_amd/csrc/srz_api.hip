@@ -288,7 +288,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (fs->pool_pending && hipEventQuery(fs->pool_ev) == hipSuccess) {
     fs->pool_pending = false;
     uint32_t need = 0;
-    for (uint32_t i = 0; i < fs->pool_n_sub; ++i) need = std::max(need, fs->h_pool_heads[i]);
+    for (uint32_t i = 0; i < fs->pool_n_sub; ++i) need = std::max(need, fs->h_pool_heads[i * CNT_STRIDE]);
     if (need > fs->pool_sub_cap) {
       HIP_TRY(ctx, hipDeviceSynchronize());
       const uint64_t cap = (uint64_t)need + need / 4u + 64u;
@@ -310,14 +310,14 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   if (fs->max_tris == 0) { // (else: k_setup resets the per-render counters)
-    HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * fs->n_frames, s));
-    HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * fs->pool_n_sub, s));
+    HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * CNT_STRIDE * fs->n_frames, s));
+    HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, s));
     HIP_TRY(ctx, hipMemsetAsync(fs->d_slow_count, 0, 2 * sizeof(uint32_t), s));
   }
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
   launch_bin(a, fs->n_frames, s);
-  HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * fs->pool_n_sub, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipEventRecord(fs->pool_ev, s));
   fs->pool_pending = true;
   if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
@@ -579,8 +579,8 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     const uint64_t cap = std::min<uint64_t>((4ull * tri_off + 4096u) / n_sub + 64u, 0xfffffff0ull / n_sub);
     fs->pool_sub_cap = (uint32_t)cap;
     FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(RasterRec) * cap * n_sub));
-    FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * 64));
-    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * 64, hipHostMallocDefault));
+    FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64)); // (one cache line per allocator)
+    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64, hipHostMallocDefault));
     FS_TRY(hipEventCreateWithFlags(&fs->pool_ev, hipEventDisableTiming));
     FS_TRY(dev_alloc((void **)&fs->d_tile_cnt, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_tile_off, sizeof(uint32_t) * fs->max_tiles));
@@ -590,7 +590,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   }
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
   FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
-  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * n_frames));
+  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * CNT_STRIDE * n_frames));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
   if (tri_off) {

@@ -18,6 +18,9 @@ constexpr int KEY_STRIDE = TILE + 1;
 // LDS row stride (dwords) of the ORDERED rasteriser's z / owner planes (k_raster_slow)
 constexpr int LDS_STRIDE = 32;
 constexpr uint32_t NO_TRI = 0xffffffffu;
+// per-frame atomic counters sit 128 bytes apart: atomics on the words of ONE cache line serialise (~10 ns each across the
+// device) as if they were one address — with 16 frames of 4096^2 that was the whole of k_raster's time
+constexpr uint32_t CNT_STRIDE = 32;
 // FrameDesc::flags, internal (set by the host): 2 lights, p == 150, every batch NORMAL / TEXTURE / PHONG → k_shade's FAST build
 constexpr uint32_t FD_FAST_SHADE = 0x100u;
 constexpr uint32_t UNLISTED = 0xffffffffu; // tile_off of a tile whose list did not fit the record pool
@@ -114,7 +117,7 @@ struct RenderArgs {
   uint32_t *redo_count;
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
   uint32_t *worklist;            // [frame][tiles per frame]: tiles (lb*tiles_x + tx) that have an owner, in arrival order
-  uint32_t *work_count;          // [frame] entries in the frame's list (zeroed by k_setup, bumped by k_raster)
+  uint32_t *work_count;          // [frame * CNT_STRIDE] entries in the frame's list (zeroed by k_setup, bumped by k_raster)
   uint32_t shade_split;          // k_shade: virtual workgroups ("lanes") per frame
   uint32_t tiles_x, n_local_bands, n_frames;
   float *out;             // [frame][4][local_rows][width]

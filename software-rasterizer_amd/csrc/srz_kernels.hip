@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.work_count[blockIdx.y] = 0u; // this frame's work list starts empty
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.work_count[blockIdx.y * CNT_STRIDE] = 0u; // this frame's work list starts empty
   if (blockIdx.x == 0 && blockIdx.y == 0) {                              // so do the record pool and the slow list
-    if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x] = 0u;
+    if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x * CNT_STRIDE] = 0u;
     if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
   }
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void k_bin(RenderArgs a) {
       uint32_t base = 0;
       if (run) {
         const uint32_t sub = wg & a.pool_sub_mask;
-        const uint32_t start = atomicAdd(&a.pool_heads[sub], run); // (also the host's measure of what the render needed)
+        const uint32_t start = atomicAdd(&a.pool_heads[sub * CNT_STRIDE], run); // (also the host's measure of what the render needed)
         base = (start <= a.pool_sub_cap && run <= a.pool_sub_cap - start) ? sub * a.pool_sub_cap + start : UNLISTED;
       }
       s_misc[0] = base, s_misc[1] = run;
@@ -880,7 +880,41 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   __builtin_amdgcn_wave_barrier();
 
   // ---- phase B: the tile's list, 64 records at a time --------------------------------------------------------------
+  // geometry of one record's bbox ∩ tile in TILE-LOCAL coordinates: V columns [x0, v-1] in nseg pieces of 8, S columns [v, x1]
+  struct Geo {
+    bool ok;
+    uint32_t nV, nS, word; // items of the two kinds; packed x0 | y0 << 5 | v << 10 | nseg << 16 | ws << 19
+    float zmin;            // nearest vertex depth
+  };
+  auto geometry = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, bool valid) {
+    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx | r3 = v_inv s_area
+    const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z);
+    const int bsx = (int16_t)(bbx & 0xffff), bsy = (int16_t)(bbx >> 16), bex = (int16_t)(bby & 0xffff), bey = (int16_t)(bby >> 16);
+    const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
+    const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
+    const int v = min(max(vend - tx0, x0), x1 + 1);
+    Geo g;
+    g.ok = valid && x0 <= x1 && y0 <= y1;
+    const uint32_t h = g.ok ? (uint32_t)(y1 - y0 + 1) : 0u, nseg = (uint32_t)(v - x0 + 7) >> 3, ws = (uint32_t)(x1 + 1 - v);
+    g.nV = __umul24(h, nseg), g.nS = __umul24(h, ws); // <= 128 / <= 224 per triangle
+    g.word = (uint32_t)x0 | ((uint32_t)y0 << 5) | ((uint32_t)v << 10) | (nseg << 16) | (ws << 19);
+    g.zmin = __builtin_fminf(__builtin_fminf(r0.z, r1.y), r2.x);
+    return g;
+  };
   const SRZ_CAS f32x4 *recs = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.pool) + off);
+  // ---- depth-ordered groups for chunks with heavy overdraw -----------------------------------------------------------
+  // The keys make the order of the triangles irrelevant, so a chunk of records that asks for several times the tile's area in
+  // pixel tests is rasterised NEAREST FIRST, in 4 groups of equal depth range of the triangles' nearest vertex (the records
+  // stay in registers); after each group the tile's farthest depth is read back, and the items of a triangle whose nearest
+  // possible depth lies behind it are dropped: they could not win a pixel.  Conservative bounds (positive depths only):
+  //   V items: 0 < alpha, beta, gamma < 1 holds for every fragment, so its depth is >= zmin = min(z0,z1,z2) less a few ulps:
+  //            bound zmin * (1 - 2^-20)
+  //   S items: the inside test is on the edge functions, not on the barycentrics, which may leave [0,1] by their rounding
+  //            error <= ~6 * 2^-24 * d^2 / |area2| (d = extent of the vertices, area2 = twice the area).  Only for triangles
+  //            with d^2 <= 2^10 |area2| (error < 4e-4): bound zmin - (zmax - zmin) / 256, then * (1 - 2^-20); slivers are
+  //            never dropped
+  uint32_t zfar = 0xffffffffu; // image of the tile's farthest depth when last read back (all ones: nothing can be dropped yet;
+                               // depths only come down, so an old value stays a valid bound)
   f32x4 n0, n1, n2, n3;
   bool nv = (uint32_t)lane < cnt;
   {
@@ -895,17 +929,30 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
       const uint32_t e = nv ? base + 64 + lane : base;
       n0 = recs[4 * e], n1 = recs[4 * e + 1], n2 = recs[4 * e + 2], n3 = recs[4 * e + 3];
     }
-    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx | r3 = v_inv s_area
-    const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z), my_idx = f2u(r2.w);
-    const int bsx = (int16_t)(bbx & 0xffff), bsy = (int16_t)(bbx >> 16), bex = (int16_t)(bby & 0xffff), bey = (int16_t)(bby >> 16);
-    // geometry of bbox ∩ tile in TILE-LOCAL coordinates: V columns [x0, v-1] in nseg pieces of 8, S columns [v, x1]
-    const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
-    const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
-    const int v = min(max(vend - tx0, x0), x1 + 1);
-    const bool ok = valid && x0 <= x1 && y0 <= y1;
-    const uint32_t h = ok ? (uint32_t)(y1 - y0 + 1) : 0u, nseg = (uint32_t)(v - x0 + 7) >> 3, ws = (uint32_t)(x1 + 1 - v);
-    const uint32_t nV = __umul24(h, nseg), nS = __umul24(h, ws); // <= 128 / <= 224 per triangle
-    const uint32_t geom = (uint32_t)x0 | ((uint32_t)y0 << 5) | ((uint32_t)v << 10) | (nseg << 16) | (ws << 19);
+    const uint32_t my_idx = f2u(r2.w);
+    const Geo G = geometry(r0, r1, r2, valid);
+    const uint32_t geom = G.word;
+    uint32_t group = 0, n_groups = 1, znear = 0, znear_s = 0; // nearest possible depth of a V / S fragment, as keys (0: unknown → kept)
+    if ((uint32_t)rl_i((int)wave_scan_add(8u * G.nV + G.nS), 63) > 4u * TILE * TILE) { // > 4 pixel tests per pixel of the tile
+      float lo = G.ok ? G.zmin : __builtin_inff(), hi = G.ok ? G.zmin : -__builtin_inff();
+      for (int o = 32; o > 0; o >>= 1) lo = __builtin_fminf(lo, __shfl_xor(lo, o)), hi = __builtin_fmaxf(hi, __shfl_xor(hi, o));
+      if (hi > lo && hi < __builtin_inff() && lo > -__builtin_inff()) {
+        n_groups = 4;
+        const float g = (G.zmin - lo) * (4.0f / (hi - lo)); // (a NaN depth → group 0)
+        group = (g > 0.0f && g < 4.0f) ? (uint32_t)g : (g >= 4.0f ? 3u : 0u);
+      }
+    }
+    if (n_groups > 1 || zfar != 0xffffffffu) {
+      if (G.zmin > 0.0f) znear = zkey_of(G.zmin * 0.99999905f);
+      const float zmax = __builtin_fmaxf(__builtin_fmaxf(r0.z, r1.y), r2.x);
+      const float dx = __builtin_fmaxf(__builtin_fmaxf(r0.x, r0.w), r1.z) - __builtin_fminf(__builtin_fminf(r0.x, r0.w), r1.z);
+      const float dy = __builtin_fmaxf(__builtin_fmaxf(r0.y, r1.x), r1.w) - __builtin_fminf(__builtin_fminf(r0.y, r1.x), r1.w);
+      const float zs = (G.zmin - (zmax - G.zmin) * 0.00390625f) * 0.99999905f;
+      if (dx * dx + dy * dy <= 1024.0f * __builtin_fabsf(r3.y) && zmax < 1e30f && zs > 0.0f) znear_s = zkey_of(zs);
+    }
+    for (uint32_t gi = 0; gi < n_groups; ++gi) {
+    const bool mine = G.ok && group == gi;
+    const uint32_t nV = (mine && znear <= zfar) ? G.nV : 0u, nS = (mine && znear_s <= zfar) ? G.nS : 0u;
     const uint32_t packed = nV | (nS << 16), incl = wave_scan_add(packed);
     const uint32_t offs = incl - packed; // exclusive: first V item | first S item << 16
     const uint32_t tot = (uint32_t)rl_i((int)incl, 63), TV = tot & 0xffffu, TS = tot >> 16;
@@ -947,9 +994,10 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
         const float z = fmaf_(al, z0, fmaf_(be, z1, ga * z2));
         // 0<al<1 & 0<be<1 & 0<ga<1  <=>  al>0 & be>0 & ga>0 & ga<1 (al+be is rounded monotonically, so ga>0 forces
         // al,be <= al+be < 1); every compare is ordered, so NaNs reject exactly like _CMP_*_OQ
-        inside[px] = (px < lim) & (al > 0.0f) & (be > 0.0f) & (ga > 0.0f) & (ga < 1.0f);
-        // a NaN depth never passes '<': min(z, +inf) turns it into a depth that loses to everything, the incoming one included
-        zk[px] = zkey_of(__builtin_fminf(z, __builtin_inff()));
+        // (a NaN alpha or beta makes gamma NaN, which fails gamma < 1: the three-way minimum may drop NaNs)
+        inside[px] = (px < lim) & (__builtin_fminf(__builtin_fminf(al, be), ga) > 0.0f) & (ga < 1.0f);
+        // (an inside fragment's depth is a sum of finite terms of bounded weights: ±inf on overflow at worst, never NaN)
+        zk[px] = zkey_of(z);
         asm volatile("" : "+v"(zk[px])); // (keeps the depth arithmetic out of the predicated blocks: 8 pixels of straight-line code)
       }
 #pragma unroll
@@ -991,7 +1039,18 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
                                __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-  }
+    // the tile's farthest depth after this group (pixels outside the frame keep +inf: no dropping there); also between the
+    // chunks of a long list once dropping has started paying
+    if (gi + 1 < n_groups || (n_groups > 1 && base + 64 < cnt)) {
+      __builtin_amdgcn_wave_barrier();
+      uint32_t zm = 0;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) zm = max(zm, (uint32_t)(s_key[(it * 2 + (lane >> 5)) * KEY_STRIDE + (lane & 31)] >> 32));
+      for (int o = 32; o > 0; o >>= 1) zm = max(zm, (uint32_t)__shfl_xor((int)zm, o));
+      zfar = zm;
+    }
+    } // groups
+  } // chunks
   __builtin_amdgcn_wave_barrier();
 
   // ---- phase C: decode the keys, write out ------------------------------------------------------------------------
@@ -1063,7 +1122,7 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
     }
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
-  if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame], 1u)] = tile;
+  if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame * CNT_STRIDE], 1u)] = tile;
 }
 
 // ================================================================================================================
@@ -1267,7 +1326,7 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         }
       }
     }
-    if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame], 1u)] = tile;
+    if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame * CNT_STRIDE], 1u)] = tile;
     __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
   }
   if (STATS) {
@@ -1558,7 +1617,7 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
     if (f >= F) continue;
     const bool frame_fast = !a.force_generic && ((as_const(a.frames) + f)->flags & FD_FAST_SHADE) != 0u;
     if (frame_fast != FAST) continue; // the other build's frame
-    const uint32_t n_work = as_const(a.work_count)[f];
+    const uint32_t n_work = as_const(a.work_count)[f * CNT_STRIDE];
     for (uint32_t w = j; w < n_work; w += S) {
       const uint32_t e = as_const(a.worklist)[(size_t)f * tpf + w];
       if constexpr (FAST)
