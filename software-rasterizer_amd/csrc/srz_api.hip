@@ -316,7 +316,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   }
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
-  launch_bin(a, fs->n_frames, s);
+  launch_bin(a, fs->n_frames, fs->max_tris, s);
   HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipEventRecord(fs->pool_ev, s));
   fs->pool_pending = true;

@@ -131,7 +131,7 @@ struct RenderArgs {
 
 void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, hipStream_t s);
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
-void launch_bin(const RenderArgs &a, int n_frames, hipStream_t s);
+void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s);
