@@ -16,7 +16,19 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(os.path.dirname(here), "gpurun_out", f"prof_{tag}")
-KERNELS = ("k_setup", "k_bands", "k_raster", "k_clear", "k_shade")
+# (matched in this order: "k_raster_slow" before "k_raster"; k_shade_fast / k_shade_generic = the two builds of k_shade)
+KERNELS = ("k_setup", "k_bin", "k_raster_slow", "k_raster", "k_clear", "k_shade_fast", "k_shade_generic")
+
+
+def kernel_of(name):
+    if "<true" in name:  # counting variants (run once, outside the timed region)
+        return None
+    if "k_shade" in name:
+        return "k_shade_fast" if "k_shade<false, true>" in name else "k_shade_generic"
+    for k in KERNELS:
+        if k in name:
+            return k
+    return None
 
 
 def one(pattern):
@@ -29,18 +41,18 @@ shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_kernel
 stats = {r["Name"]: r for r in csv.DictReader(open(one("trace/**/*kernel_stats.csv")))}
 per_kernel_us = {}
 for name, r in stats.items():
-    for k in KERNELS:
-        if k in name and "<true>" not in name:
-            per_kernel_us[k] = float(r["AverageNs"]) / 1e3
+    k = kernel_of(name)
+    if k:
+        per_kernel_us[k] = float(r["AverageNs"]) / 1e3
 
 
 def pmc(dirname):
     rows = list(csv.DictReader(open(one(f"{dirname}/**/*counter_collection.csv"))))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
-        for k in KERNELS:
-            if k in r["Kernel_Name"] and "<true>" not in r["Kernel_Name"]:
-                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = kernel_of(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
@@ -68,3 +80,21 @@ t[bench["config"]["workload"]] = {"hbm_bytes_per_launch": tot_w + 2 * tot_f, "fr
 json.dump(t, open(tfile, "w"), indent=1)
 print(json.dumps(out["hbm_bytes_per_launch"], indent=1))
 print(per_kernel_us, "events total ms:", bench["roofline"]["launch_ms"])
+
+# ---- the other BASELINE configs (tests/perf_probe.py under the same two profiler modes) ---------------------------------
+others = {}
+for n, label in ((3, "spot_bunny_phong_1080p x64"), (4, "spot_x16_texture_2048 x32"), (5, "spot_x8_overdraw_4096 x16")):
+    try:
+        shutil.copy(one(f"trace_c{n}/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_c{n}_kernel_stats.csv"))
+        us = {}
+        for r in csv.DictReader(open(one(f"trace_c{n}/**/*kernel_stats.csv"))):
+            k = kernel_of(r["Name"])
+            if k:
+                us[k] = float(r["AverageNs"]) / 1e3
+        others[f"config{n}"] = {"workload": label, "avg_kernel_us": us, "sq_avg_per_launch": pmc(f"pmc_sq_c{n}")}
+    except AssertionError:
+        pass
+if others:
+    json.dump(others, open(os.path.join(here, f"{tag}_configs_pmc.json"), "w"), indent=1)
+    for k, v in others.items():
+        print(k, {a: round(b) for a, b in v["avg_kernel_us"].items()})
