@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 HBM_MEASURED_COPY_GBS = 6290.0
 XGMI_LINK_GBS = 153.0  # per link, per direction (7 links per GPU)
 # the other GPU configs of BASELINE.json, whole frames on one GPU: (workload, frames per step, steps)
-EXTRA_CASES = [("spot_bunny_phong_1080p", 64, 10), ("spot_x16_texture_2048", 32, 10), ("spot_x8_overdraw_4096", 16, 10),
+EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 10), ("spot_x16_texture_2048", 64, 10), ("spot_x8_overdraw_4096", 32, 10),
                ("readme_spot_crate_1024", 256, 10)]  # (+ the scene of the reference's one published raster figure)
 
 
@@ -369,7 +369,7 @@ def main():
         for (w, f, s, scope) in todo:
             try:
                 c = Case(ctx, torch, w, f, scope, 1)
-                d, k, ps = time_single_gpu(c, s, 2, fence)
+                d, k, ps = time_single_gpu(c, s, 3, fence)
                 extras.append(case_record(c, s, d, k, ps, c.stats["fragments"], c.stats["visible"]))
                 c.close()
             except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)

@@ -328,7 +328,13 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   unsigned ev = 0;
   if (side) {
     if (!ctx->stream2) {
-      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      // The clear must run BESIDE the launch stream, so it may not share a hardware queue with it: HIP deals its streams
+      // round-robin onto a few hardware queues (seen: the caller's stream and this one on the same queue — the clear then ran
+      // in front of k_raster instead of beside it, +20 % per render).  Streams of another priority live on queues of their own;
+      // the clear is throttled by its grid size, not by priority, so the highest one costs the rasteriser nothing.
+      int prio_least = 0, prio_greatest = 0;
+      HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+      HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_greatest));
       for (int i = 0; i < srz_ctx::EV_RING; ++i) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
