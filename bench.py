@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 HBM_MEASURED_COPY_GBS = 6290.0
 XGMI_LINK_GBS = 153.0  # per link, per direction (7 links per GPU)
 # the other GPU configs of BASELINE.json, whole frames on one GPU: (workload, frames per step, steps)
-EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 10), ("spot_x16_texture_2048", 64, 10), ("spot_x8_overdraw_4096", 32, 10),
-               ("readme_spot_crate_1024", 256, 10)]  # (+ the scene of the reference's one published raster figure)
+EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 64, 20), ("spot_x8_overdraw_4096", 32, 20),
+               ("readme_spot_crate_1024", 256, 20)]  # (+ the scene of the reference's one published raster figure)
 
 
 def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
@@ -129,41 +129,78 @@ class Case:
             wl.upload_meshes(ctx)
             suniq = [wl.scene_frame(i) for i in range(min(n_frames, 36))]
             frames = [suniq[i % len(suniq)] for i in range(n_frames)]
+        self.frames, self._lanes = frames, None
         self.fs = ctx.frameset(frames)
         self.stats = self.fs.stats()  # counting variant of the kernels, run once, outside every timed region
         self.algo_bytes = self.fs.algorithmic_bytes()
         self.n_frames, self.frames_per_gpu = n_frames, frames_per_gpu
         self.out = [torch.empty(self.fs.out_shape, dtype=torch.float32, device="cuda") for _ in range(n_out)]
 
+    def lanes(self, n):
+        """the same frames as n lane framesets on n streams (srz.parallel.LaneRenderer), built once"""
+        from srz import parallel
+        if self._lanes is None:
+            self._lanes = parallel.LaneRenderer(self.ctx, self.frames, n)
+        return self._lanes
+
     def close(self):
         self.out = None
         self.fs.close()
+        if self._lanes is not None:
+            self._lanes.close()
         self.torch.cuda.empty_cache()
 
 
-def time_single_gpu(case, steps, warmup, fence):
-    """W warm-up steps, then EXACTLY K steps bracketed by fences; per-step device times from events on the render stream."""
+def time_single_gpu(case, steps, warmup, fence, lanes=2):
+    """W warm-up steps, then EXACTLY K steps bracketed by fences.
+
+    A step renders the whole batch: `lanes` runs of whole frames, each on a stream of its own (srz.parallel.LaneRenderer —
+    the lanes are not synchronised with each other, so consecutive steps overlap at their edges; every step is complete
+    before the closing fence).  Inside the timed region every render carries two HIP events on its stream (start / end of
+    its launch set); the device time of the region is the span from the first start to the last end.  The per-kernel split
+    comes from a short pass AFTER the timed region — the batch in one piece on one stream, with two more events per render:
+    each event is a barrier in the stream, so the split is kept out of the throughput measurement."""
     torch, ctx, fs = case.torch, case.ctx, case.fs
     from srz import abi
-    stream = torch.cuda.Stream()
     out = case.out[0]
-    with torch.cuda.stream(stream):
-        for _ in range(warmup):
-            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
-        fence()
-        ctx.set_kernel_timing(True)
-        ctx.kernel_time_ms(reset=True)
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        t0 = time.perf_counter()
-        evs[0].record(stream)
-        for k in range(steps):
-            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
-            evs[k + 1].record(stream)
-        fence()
-        dt = time.perf_counter() - t0
+    lr = case.lanes(lanes)
+    for _ in range(warmup):
+        lr.render(out.data_ptr(), abi.FUSED_CLEAR)
+    fence()
+    ctx.set_kernel_timing(1)
+    ctx.kernel_time_ms(reset=True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        lr.render(out.data_ptr(), abi.FUSED_CLEAR)
+    fence()
+    dt = time.perf_counter() - t0
+    samples, span_ms = ctx.kernel_time_samples()
     kt = ctx.kernel_time_ms(reset=True)
-    ctx.set_kernel_timing(False)
-    per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+    n_l = len(lr.sets)
+    per_step = [max(samples[i:i + n_l]) for i in range(0, len(samples) - n_l + 1, n_l)]  # a step ends with its slowest lane
+    kt["lane_launch_ms"], kt["total_ms"], kt["lanes"] = kt["total_ms"], span_ms / max(steps, 1), n_l
+    # ---- not part of the measurement: the same batch in ONE piece on ONE stream (whole-launch time, then the kernel split)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+        fence()
+        n1 = min(steps, 20)
+        t1 = time.perf_counter()
+        for k in range(n1):
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+        fence()
+        kt["one_stream_ms_per_step"] = (time.perf_counter() - t1) / n1 * 1e3
+        ctx.set_kernel_timing(2)
+        ctx.kernel_time_ms(reset=True)
+        for k in range(min(steps, 5)):
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+        fence()
+        split = ctx.kernel_time_ms(reset=True)
+    ctx.set_kernel_timing(0)
+    for k in ("bin_ms", "raster_ms", "shade_ms"):
+        kt[k] = split[k]
+    kt["split_total_ms"] = split["total_ms"]
     return dt, kt, per_step
 
 
@@ -182,15 +219,19 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
         "fragments_per_frame": frag_total / fs.n_frames, "visible_pixels_per_frame": vis_total / fs.n_frames,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
-                     "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]},
+                     "lanes": kt.get("lanes", 1), "lane_launch_ms": kt.get("lane_launch_ms"),
+                     "one_stream": {"ms_per_step": kt.get("one_stream_ms_per_step"), "launch_ms": kt.get("split_total_ms"),
+                                    "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]}},
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15,
+                    help="untimed steps first; the first ~13 steps after idle run up to 10 %% slower (clock ramp, first-touch "
+                         "of the record pool): tests/step_series_probe.py prints the series")
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", default="spot_texture_1024")
     ap.add_argument("--scope", choices=["raster", "draw"], default="raster",
@@ -199,6 +240,9 @@ def main():
     ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
                     help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
                          "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="N=1: the batch is rendered as this many runs of whole frames on streams of their own "
+                         "(srz.parallel.LaneRenderer); 1 = one frameset on one stream")
     ap.add_argument("--no-overlap", action="store_true", help="N>1 only: render and exchange back to back on one stream")
     ap.add_argument("--no-extras", action="store_true", help="N=1: skip the other BASELINE configs / scope draw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,7 +295,7 @@ def main():
 
     multi = None
     if world == 1:
-        dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence)
+        dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes)
     else:
         # ---- N > 1: render on one stream, exchange (all-gather + de-interleave) on another, double-buffered ------------
         what = abi.EXCHANGE_PLANES if args.exchange == "planes" else abi.EXCHANGE_BGR8
@@ -284,7 +328,7 @@ def main():
             pipe.step()
         pipe.drain()
         fence()
-        ctx.set_kernel_timing(True)
+        ctx.set_kernel_timing(1)
         ctx.kernel_time_ms(reset=True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -337,9 +381,12 @@ def main():
                                         "(not measured in this run)") if traffic else None,
                      "frac_of_measured_copy_6290": roof["achieved"] / HBM_MEASURED_COPY_GBS,
                      "kernel": "hot path = k_setup + k_bin + k_raster (+ k_raster_slow) + k_shade in line, k_clear beside k_raster/k_shade "
-                               "on a second stream (one launch each per step)",
+                               "on a second stream (one launch each per lane per step)",
                      "launches_timed": kt["launches"],
-                     "note": "rank 0's shard; HIP events on the launch stream; algorithmic bytes = "
+                     "note": "rank 0's shard. launch_ms = device time of the timed region (HIP events: first launch set's start to "
+                             "the last one's end) / steps — the lanes' launch sets overlap, lane_launch_ms is one lane's own "
+                             "start-to-end; one_stream = the batch in one piece on one stream, measured after the timed region "
+                             "(where the per-kernel split comes from). algorithmic bytes = "
                              "16*W*rows + 96*N_tri + 24*N_lights + min(3*texW*texH, 3*textured_px) per frame"})
         res = {
             "metric": "frames_per_sec", "value": rec["frames_per_sec"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -369,7 +416,7 @@ def main():
         for (w, f, s, scope) in todo:
             try:
                 c = Case(ctx, torch, w, f, scope, 1)
-                d, k, ps = time_single_gpu(c, s, 3, fence)
+                d, k, ps = time_single_gpu(c, s, 8, fence, args.lanes)
                 extras.append(case_record(c, s, d, k, ps, c.stats["fragments"], c.stats["visible"]))
                 c.close()
             except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)

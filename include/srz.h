@@ -252,6 +252,13 @@ uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *
  * the launch stream: ms4[0] = setup+binning kernels, ms4[1] = raster kernel (visibility), ms4[2] = shade kernel up to
  * the join with the clear kernel that runs beside both on a second stream, ms4[3] = whole pipeline. */
 int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches);
+/* ms4[3] of each timed render since the last reset, in submission order (at most cap values, *n = how many): the
+ * per-step distribution (p10 / median / p90) bench.py prints; *span_ms (may be NULL) = from the first of them starting
+ * to the last of them ending — renders submitted to different streams overlap, the span is what they took together.
+ * Call it before the resetting srz_kernel_time_ms. */
+int srz_kernel_time_samples(srz_ctx *ctx, float *out, int cap, int *n, double *span_ms);
+/* enabled: 0 off; 1 the whole launch set only (ms4[3]; two events per render); 2 also the three groups (four events per
+ * render — every event is a barrier in the launch stream, ≈4 µs each, so throughput is measured with 1 and broken down with 2) */
 int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
 int srz_sync(srz_ctx *ctx);
 /* self-check of the device arithmetic: compares the kernels' short exact reciprocal / square-root sequences with the

@@ -19,7 +19,8 @@ namespace {
 std::string g_create_error;
 
 struct EventPair {
-  hipEvent_t t0, t1, t2, t3; // t0..t1 setup+bands, t1..t2 raster (visibility + clear), t2..t3 shade
+  hipEvent_t t0, t1, t2, t3; // t0..t1 setup+binning, t1..t2 raster (visibility + clear), t2..t3 shade
+  bool detailed;             // t1 / t2 were recorded (every recorded event is a barrier in the launch stream: ≈4 µs each)
 };
 } // namespace
 
@@ -37,11 +38,17 @@ struct srz_ctx {
     uint32_t *d_faces = nullptr;
     uint32_t n_verts = 0, n_faces = 0;
   } mesh[MAX_MESH];
-  bool timing = false;
+  int timing = 0; // 0 off, 1 whole launch set only (2 events per render), 2 per-kernel groups as well (4 events)
   std::vector<EventPair> ev_pool, ev_used;
   double acc_ms[4] = {0, 0, 0, 0}; // bin, raster, shade, total
   uint64_t tex_version = 1;
   int acc_launches = 0;
+  std::vector<float> acc_samples; // whole-launch-set time of every timed render since the last reset (bounded)
+  // span of the timed renders since the last reset: first t0 → latest t3 (renders on several streams overlap; the span is
+  // what their launch sets took together)
+  hipEvent_t span_t0 = nullptr;
+  bool span_open = false;
+  double span_ms = 0.0;
   unsigned long long dbg[ST_COUNT] = {};
   // srz_draw / srz_draw_scene keep their frameset and device framebuffer between calls: a call whose structure (size,
   // batch sizes, shader types, light count) equals the previous one only re-uploads the data
@@ -248,12 +255,23 @@ int collect_events(srz_ctx *ctx) {
   for (auto &ep : ctx->ev_used) {
     HIP_TRY(ctx, hipEventSynchronize(ep.t3));
     float b = 0.f, r = 0.f, sh = 0.f, t = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&b, ep.t0, ep.t1));
-    HIP_TRY(ctx, hipEventElapsedTime(&r, ep.t1, ep.t2));
-    HIP_TRY(ctx, hipEventElapsedTime(&sh, ep.t2, ep.t3));
+    if (ep.detailed) {
+      HIP_TRY(ctx, hipEventElapsedTime(&b, ep.t0, ep.t1));
+      HIP_TRY(ctx, hipEventElapsedTime(&r, ep.t1, ep.t2));
+      HIP_TRY(ctx, hipEventElapsedTime(&sh, ep.t2, ep.t3));
+    }
     HIP_TRY(ctx, hipEventElapsedTime(&t, ep.t0, ep.t3));
     ctx->acc_ms[0] += b, ctx->acc_ms[1] += r, ctx->acc_ms[2] += sh, ctx->acc_ms[3] += t;
     ctx->acc_launches++;
+    if (ctx->acc_samples.size() < 65536) ctx->acc_samples.push_back(t);
+    if (!ctx->span_open) { // keep the first render's start: swap it for the context's spare event
+      if (!ctx->span_t0) HIP_TRY(ctx, hipEventCreate(&ctx->span_t0));
+      std::swap(ctx->span_t0, ep.t0);
+      ctx->span_open = true;
+    }
+    float sp = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&sp, ctx->span_t0, ep.t3));
+    ctx->span_ms = std::max(ctx->span_ms, (double)sp);
     ctx->ev_pool.push_back(ep);
   }
   ctx->ev_used.clear();
@@ -302,10 +320,11 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   RenderArgs a = make_args(ctx, fs, d_out, flags_or);
   a.force_ordered = a.force_generic = stats ? 1u : 0u; // the counters are those of the reference's ordered walk
   EventPair ep{};
-  bool timed = ctx->timing && !stats && ctx->ev_used.size() < 65536;
+  const bool timed = ctx->timing != 0 && !stats && ctx->ev_used.size() < 65536, detailed = timed && ctx->timing >= 2;
   if (timed) {
     int rc = get_events(ctx, ep);
     if (rc) return rc;
+    ep.detailed = detailed;
     HIP_TRY(ctx, hipEventRecord(ep.t0, s));
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
@@ -317,10 +336,15 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
   launch_bin(a, fs->n_frames, fs->max_tris, s);
-  HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipEventRecord(fs->pool_ev, s));
-  fs->pool_pending = true;
-  if (timed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
+  // what this render asked of the record pool goes back to the host (read by the NEXT render): on the side stream behind the
+  // clear when there is one — a copy in the launch stream here would sit between k_bin and k_raster (≈15 µs)
+  auto read_back_demand = [&](hipStream_t cs) {
+    HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipEventRecord(fs->pool_ev, cs));
+    fs->pool_pending = true;
+    return (int)SRZ_OK;
+  };
+  if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in line (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
@@ -342,16 +366,19 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     }
     ev = ctx->ev_next++ % srz_ctx::EV_RING;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[ev], s));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork[ev], 0));
-    launch_clear(a, fs->max_tiles, true, ctx->stream2);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], ctx->stream2));
+    hipStream_t side_s = ctx->stream2;
+    HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
+    launch_clear(a, fs->max_tiles, true, side_s);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
+    if (int rc = read_back_demand(side_s)) return rc; // (after the join event: not on the render's critical path)
   } else if (any_fused) {
     launch_clear(a, fs->max_tiles, false, s);
   }
   launch_raster(a, fs->n_frames, stats, s);
-  if (timed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
+  if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, fs->any_fast, fs->any_generic, s);
   if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
+  else if (int rc = read_back_demand(s)) return rc;
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -436,6 +463,7 @@ void srz_destroy(srz_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->draw_fs) srz_frameset_destroy(ctx, ctx->draw_fs);
   (void)hipFree(ctx->draw_out);
+  if (ctx->span_t0) (void)hipEventDestroy(ctx->span_t0);
   for (auto &ep : ctx->ev_used) ctx->ev_pool.push_back(ep);
   for (auto &ep : ctx->ev_pool) (void)hipEventDestroy(ep.t0), (void)hipEventDestroy(ep.t1), (void)hipEventDestroy(ep.t2), (void)hipEventDestroy(ep.t3);
   for (int i = 0; i < MAX_TEX; ++i) (void)hipFree(ctx->d_texmem[i]);
@@ -957,7 +985,7 @@ uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *
 
 int srz_set_kernel_timing(srz_ctx *ctx, int enabled) {
   if (!ctx) return SRZ_E_INVALID;
-  ctx->timing = enabled != 0;
+  ctx->timing = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
   return SRZ_OK;
 }
 
@@ -969,7 +997,25 @@ int srz_kernel_time_ms(srz_ctx *ctx, int reset, double *ms4, int *launches) {
   for (int i = 0; i < 4; ++i)
     if (ms4) ms4[i] = ctx->acc_launches ? ctx->acc_ms[i] / ctx->acc_launches : 0.0;
   if (launches) *launches = ctx->acc_launches;
-  if (reset) ctx->acc_ms[0] = ctx->acc_ms[1] = ctx->acc_ms[2] = ctx->acc_ms[3] = 0.0, ctx->acc_launches = 0;
+  if (reset) {
+    ctx->acc_ms[0] = ctx->acc_ms[1] = ctx->acc_ms[2] = ctx->acc_ms[3] = 0.0, ctx->acc_launches = 0, ctx->acc_samples.clear();
+    ctx->span_open = false, ctx->span_ms = 0.0;
+  }
+  return SRZ_OK;
+}
+
+/* the whole-launch-set time (ms) of each timed render since the last reset, in submission order, and the span from the
+ * first one's start to the latest end (renders submitted to different streams overlap: the span is what they took
+ * together).  Call before the resetting srz_kernel_time_ms.  *n = values written (at most cap) */
+int srz_kernel_time_samples(srz_ctx *ctx, float *out, int cap, int *n, double *span_ms) {
+  if (!ctx || !n || (cap > 0 && !out)) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = collect_events(ctx);
+  if (rc) return rc;
+  int m = (int)std::min<size_t>(ctx->acc_samples.size(), (size_t)std::max(cap, 0));
+  for (int i = 0; i < m; ++i) out[i] = ctx->acc_samples[i];
+  *n = m;
+  if (span_ms) *span_ms = ctx->span_ms;
   return SRZ_OK;
 }
 

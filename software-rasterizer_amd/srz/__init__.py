@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch",
+           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch",
            "srz_comm_unique_id", "srz_comm_create", "srz_comm_destroy", "srz_frameset_exchange_bytes", "srz_frameset_allgather",
            "srz_frameset_deinterleave"]
 
@@ -62,6 +62,7 @@ def lib():
         L.srz_frameset_algorithmic_bytes.restype = C.c_uint64
         L.srz_kernel_time_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.srz_set_kernel_timing.argtypes = [vp, C.c_int]
+        L.srz_kernel_time_samples.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.srz_sync.argtypes = [vp]
         L.srz_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.srz_verify_fastmath.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -234,12 +235,20 @@ class Context:
         return FrameSet(self, frames)
 
     def set_kernel_timing(self, on):
-        self._check(lib().srz_set_kernel_timing(self.h, 1 if on else 0))
+        """False/0: off; 1: whole launch set only (2 events per render); True/2: per-kernel groups as well (4 events)"""
+        self._check(lib().srz_set_kernel_timing(self.h, 2 if on is True else int(on)))
 
     def kernel_time_ms(self, reset=True):
         ms, n = (C.c_double * 4)(), C.c_int()
         self._check(lib().srz_kernel_time_ms(self.h, 1 if reset else 0, ms, C.byref(n)))
         return {"bin_ms": ms[0], "raster_ms": ms[1], "shade_ms": ms[2], "total_ms": ms[3], "launches": n.value}
+
+    def kernel_time_samples(self, cap=65536):
+        """(per-render launch-set ms since the last reset, span ms from the first start to the last end); read it BEFORE
+        kernel_time_ms(reset=True)"""
+        out, n, span = (C.c_float * cap)(), C.c_int(), C.c_double()
+        self._check(lib().srz_kernel_time_samples(self.h, out, cap, C.byref(n), C.byref(span)))
+        return [float(out[i]) for i in range(n.value)], span.value
 
     def verify_fastmath(self):
         out = (C.c_uint64 * 4)()

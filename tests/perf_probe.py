@@ -34,8 +34,10 @@ fs = ctx.frameset(frames)
 st = fs.stats()
 print("stats", st)
 out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
-stream = torch.cuda.current_stream().cuda_stream
-ctx.set_kernel_timing(not os.environ.get('PROBE_NO_TIMING'))
+_sk = os.environ.get('PROBE_STREAM', 'null')  # null | new | high : which stream the renders go to
+_ts = torch.cuda.current_stream() if _sk == 'null' else torch.cuda.Stream(priority=-1 if _sk == 'high' else 0)
+stream = _ts.cuda_stream
+ctx.set_kernel_timing(int(os.environ.get('PROBE_TIMING', '2')))
 for _ in range(3):
     fs.render(out.data_ptr(), fs.out_bytes, BASE_FLAGS | dbg, stream)
 torch.cuda.synchronize()
@@ -49,4 +51,4 @@ kt = ctx.kernel_time_ms(True)
 ab = fs.algorithmic_bytes()
 print(f"F={F} wall/render={dt*1e3:.3f} ms  " + " ".join(f"{k}={v:.3f}" if k != "launches" else f"{k}={v}" for k, v in kt.items()))
 print(f"frames/s={F/dt:.0f}  Mfrag/s={st['fragments']/dt/1e6:.1f}  algorithmic bytes={ab/1e6:.1f} MB  "
-      f"achieved={ab/(kt['total_ms']*1e-3)/1e9:.1f} GB/s (pipeline, events)  {ab/dt/1e9:.1f} GB/s (wall)")
+      f"achieved={ab/(max(kt['total_ms'], 1e-9)*1e-3)/1e9:.1f} GB/s (pipeline, events)  {ab/dt/1e9:.1f} GB/s (wall)")

@@ -268,3 +268,39 @@ def test_srz_draw_reuses_its_frameset_between_calls(orc):
     for p in range(4):
         assert np.array_equal(bits(gpu[p]), bits(ref[p])), p
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_lane_renderer_equals_one_frameset_and_timing_samples():
+    """a batch as 2 / 3 lanes (framesets on streams of their own) gives the bytes of the batch as one frameset, batch after
+    batch; the context's per-render samples and their span are consistent"""
+    import srz
+    ctx = srz.Context(0)
+    frames = [scenes.config2(i, size=256) for i in range(20)]
+    ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    fs = ctx.frameset(frames)
+    ref = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    fs.render(ref.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR)
+    torch.cuda.synchronize()
+    for lanes in (2, 3):
+        lr = parallel.LaneRenderer(ctx, frames, lanes)
+        assert lr.cuts[0] == 0 and lr.cuts[-1] == 20 and all(a < b for a, b in zip(lr.cuts, lr.cuts[1:]))
+        assert lr.out_shape == fs.out_shape and lr.out_bytes == fs.out_bytes
+        out = torch.full(lr.out_shape, float("nan"), dtype=torch.float32, device="cuda")
+        ctx.set_kernel_timing(1)
+        ctx.kernel_time_ms(reset=True)
+        for _ in range(3):  # back to back: the lanes overlap across batches
+            lr.render(out.data_ptr(), abi.FUSED_CLEAR)
+        lr.synchronize()
+        samples, span = ctx.kernel_time_samples()
+        kt = ctx.kernel_time_ms(reset=True)
+        ctx.set_kernel_timing(0)
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+        assert len(samples) == 3 * lanes == kt["launches"] and all(x > 0 for x in samples)
+        assert max(samples) <= span * 1.001 and span <= sum(samples) * 1.5
+        assert kt["bin_ms"] == 0 and abs(kt["total_ms"] - sum(samples) / len(samples)) < 1e-3
+        st = lr.stats()  # (the texture term of the algorithmic bytes needs the counters)
+        assert st == fs.stats()
+        assert lr.algorithmic_bytes() == fs.algorithmic_bytes()
+        lr.close()
+    fs.close()
