@@ -129,7 +129,7 @@ class Case:
             wl.upload_meshes(ctx)
             suniq = [wl.scene_frame(i) for i in range(min(n_frames, 36))]
             frames = [suniq[i % len(suniq)] for i in range(n_frames)]
-        self.frames, self._lanes = frames, None
+        self.frames, self._lanes = frames, {}
         self.fs = ctx.frameset(frames)
         self.stats = self.fs.stats()  # counting variant of the kernels, run once, outside every timed region
         self.algo_bytes = self.fs.algorithmic_bytes()
@@ -137,17 +137,17 @@ class Case:
         self.out = [torch.empty(self.fs.out_shape, dtype=torch.float32, device="cuda") for _ in range(n_out)]
 
     def lanes(self, n):
-        """the same frames as n lane framesets on n streams (srz.parallel.LaneRenderer), built once"""
+        """the same frames as n lane framesets on n streams (srz.parallel.LaneRenderer), built once per n"""
         from srz import parallel
-        if self._lanes is None:
-            self._lanes = parallel.LaneRenderer(self.ctx, self.frames, n)
-        return self._lanes
+        if n not in self._lanes:
+            self._lanes[n] = parallel.LaneRenderer(self.ctx, self.frames, n)
+        return self._lanes[n]
 
     def close(self):
         self.out = None
         self.fs.close()
-        if self._lanes is not None:
-            self._lanes.close()
+        for lr in self._lanes.values():
+            lr.close()
         self.torch.cuda.empty_cache()
 
 
@@ -163,6 +163,20 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     torch, ctx, fs = case.torch, case.ctx, case.fs
     from srz import abi
     out = case.out[0]
+    calibration = None
+    if lanes <= 0:  # auto: a short untimed comparison of one stream against two lanes picks the layout of the timed region
+        calibration = {}
+        for n_l in (1, 2):
+            cand = case.lanes(n_l)
+            for _ in range(6):
+                cand.render(out.data_ptr(), abi.FUSED_CLEAR)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(12):
+                cand.render(out.data_ptr(), abi.FUSED_CLEAR)
+            fence()
+            calibration[n_l] = (time.perf_counter() - t0) / 12 * 1e3
+        lanes = min(calibration, key=calibration.get)
     lr = case.lanes(lanes)
     for _ in range(warmup):
         lr.render(out.data_ptr(), abi.FUSED_CLEAR)
@@ -179,6 +193,7 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     n_l = len(lr.sets)
     per_step = [max(samples[i:i + n_l]) for i in range(0, len(samples) - n_l + 1, n_l)]  # a step ends with its slowest lane
     kt["lane_launch_ms"], kt["total_ms"], kt["lanes"] = kt["total_ms"], span_ms / max(steps, 1), n_l
+    kt["lanes_calibration_ms"] = calibration
     # ---- not part of the measurement: the same batch in ONE piece on ONE stream (whole-launch time, then the kernel split)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -210,7 +225,7 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
     pipeline_s = kt["total_ms"] * 1e-3
     achieved = case.algo_bytes / pipeline_s / 1e9 if pipeline_s > 0 else 0.0
     return {
-        "workload": case.name, "scope": case.scope, "width": fs.width, "height": fs.height,
+        "workload": case.name, "scope": case.scope, "lanes": kt.get("lanes", 1), "width": fs.width, "height": fs.height,
         "frames_per_step": case.n_frames, "triangles_per_frame": case.tris_per_frame, "steps": steps,
         "frames_per_sec": fps, "ms_per_step": dt / steps * 1e3,
         "ms_per_step_p10_median_p90": [pct(per_step, 0.1), pct(per_step, 0.5), pct(per_step, 0.9)] if per_step else None,
@@ -220,6 +235,7 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
                      "lanes": kt.get("lanes", 1), "lane_launch_ms": kt.get("lane_launch_ms"),
+                     "lanes_calibration_ms_per_step": kt.get("lanes_calibration_ms"),
                      "one_stream": {"ms_per_step": kt.get("one_stream_ms_per_step"), "launch_ms": kt.get("split_total_ms"),
                                     "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]}},
     }
@@ -240,9 +256,10 @@ def main():
     ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
                     help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
                          "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=1,
                     help="N=1: the batch is rendered as this many runs of whole frames on streams of their own "
-                         "(srz.parallel.LaneRenderer); 1 = one frameset on one stream")
+                         "(srz.parallel.LaneRenderer); 1 = one frameset on one stream; 0 = whichever of 1 and 2 a short "
+                         "untimed comparison before the warm-up finds faster")
     ap.add_argument("--no-overlap", action="store_true", help="N>1 only: render and exchange back to back on one stream")
     ap.add_argument("--no-extras", action="store_true", help="N=1: skip the other BASELINE configs / scope draw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -411,12 +428,14 @@ def main():
     # ---- N = 1: the other GPU configs of BASELINE.json + configs[1] at scope draw, each outside the headline's timed region
     if world == 1 and not args.no_extras:
         extras = []
-        todo = [(w, f, s, "raster") for (w, f, s) in EXTRA_CASES if w != args.workload]
-        todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster"))
-        for (w, f, s, scope) in todo:
+        todo = [(w, f, s, "raster", args.lanes) for (w, f, s) in EXTRA_CASES if w != args.workload]
+        todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster", args.lanes))
+        # the headline workload once more as two lanes on two streams (consecutive batches overlap at their edges)
+        todo.append((args.workload, args.frames, args.steps, args.scope, 2 if args.lanes == 1 else 1))
+        for (w, f, s, scope, n_lanes) in todo:
             try:
                 c = Case(ctx, torch, w, f, scope, 1)
-                d, k, ps = time_single_gpu(c, s, 8, fence, args.lanes)
+                d, k, ps = time_single_gpu(c, s, 15 if w == args.workload else 8, fence, n_lanes)
                 extras.append(case_record(c, s, d, k, ps, c.stats["fragments"], c.stats["visible"]))
                 c.close()
             except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)

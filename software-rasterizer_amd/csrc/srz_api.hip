@@ -59,6 +59,14 @@ struct srz_ctx {
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
   hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
   unsigned ev_next = 0;
+  // Renders submitted to DIFFERENT streams (LaneRenderer) take turns in the setup..raster phase: the next one's k_setup waits
+  // for the previous one's k_raster.  Two k_rasters side by side slow each other (both LDS-bound) and then leave two k_shades
+  // side by side (both VALU-bound); taking turns puts one stream's raster beside the other's shade, which is the overlap that
+  // pays (MI355X, 2 x 128 frames of 1024^2: 1.13 → 1.09 ms per batch).  Renders on one stream are unaffected.
+  hipEvent_t ev_raster[EV_RING] = {};
+  unsigned raster_next = 0;
+  hipStream_t raster_last_stream = nullptr;
+  bool raster_valid = false;
 };
 
 struct srz_target {
@@ -220,11 +228,8 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.vis = fs->d_vis;
   a.worklist = fs->d_worklist;
   a.work_count = fs->d_work_count;
-  // k_shade lanes per frame: >= 128 (one or two tiles per virtual workgroup at 1024^2), and at least 4 virtual
-  // workgroups per physical one when the batch has few frames
-  static const uint32_t split = getenv("SRZ_SHADE_SPLIT") ? (uint32_t)atoi(getenv("SRZ_SHADE_SPLIT")) : 0u;
-  const uint32_t grid = fs->max_tiles < 4096u ? fs->max_tiles : 4096u, fpad = fs->n_frames < 8 ? (uint32_t)fs->n_frames : ((uint32_t)fs->n_frames + 7u) / 8u * 8u;
-  a.shade_split = split ? split : std::max(128u, 4u * grid / std::max(fpad, 1u));
+  // (a list holds the tiles of every 8th frame; of fewer than 8 frames: any of them)
+  a.work_cap = (uint32_t)(fs->n_frames < 8 ? fs->n_frames : (fs->n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x;
   a.tiles_x = fs->tiles_x;
   a.n_local_bands = fs->n_local_bands;
   a.n_frames = (uint32_t)fs->n_frames;
@@ -329,9 +334,16 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   }
   if (stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   if (fs->max_tris == 0) { // (else: k_setup resets the per-render counters)
-    HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * CNT_STRIDE * fs->n_frames, s));
+    HIP_TRY(ctx, hipMemsetAsync(fs->d_work_count, 0, sizeof(uint32_t) * CNT_STRIDE * N_WORK_LISTS, s));
     HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, s));
     HIP_TRY(ctx, hipMemsetAsync(fs->d_slow_count, 0, 2 * sizeof(uint32_t), s));
+  }
+  const bool turns = !stats && fs->max_tiles >= 8192; // (batches; small jobs are launch-bound and gain nothing)
+  if (turns) {
+    if (!ctx->ev_raster[0])
+      for (int i = 0; i < srz_ctx::EV_RING; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_raster[i], hipEventDisableTiming));
+    if (ctx->raster_valid && ctx->raster_last_stream != s)
+      HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_raster[(ctx->raster_next + srz_ctx::EV_RING - 1) % srz_ctx::EV_RING], 0));
   }
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
@@ -375,6 +387,10 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     launch_clear(a, fs->max_tiles, false, s);
   }
   launch_raster(a, fs->n_frames, stats, s);
+  if (turns) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_raster[ctx->raster_next++ % srz_ctx::EV_RING], s));
+    ctx->raster_last_stream = s, ctx->raster_valid = true;
+  }
   if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, fs->any_fast, fs->any_generic, s);
   if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
@@ -474,6 +490,9 @@ void srz_destroy(srz_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream2);
     for (int i = 0; i < srz_ctx::EV_RING; ++i) (void)hipEventDestroy(ctx->ev_fork[i]), (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  if (ctx->ev_raster[0]) {
+    for (int i = 0; i < srz_ctx::EV_RING; ++i) (void)hipEventDestroy(ctx->ev_raster[i]);
   }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -623,8 +642,8 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint32_t) * fs->max_tiles));
   }
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)n_frames * fs->local_rows * (size_t)W));
-  FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * fs->max_tiles));
-  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * CNT_STRIDE * n_frames));
+  FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint32_t) * N_WORK_LISTS * (size_t)(n_frames < 8 ? n_frames : (n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x));
+  FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * CNT_STRIDE * N_WORK_LISTS));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
   if (tri_off) {

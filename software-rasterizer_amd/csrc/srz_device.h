@@ -23,6 +23,7 @@ constexpr uint32_t NO_TRI = 0xffffffffu;
 constexpr uint32_t CNT_STRIDE = 32;
 // FrameDesc::flags, internal (set by the host): 2 lights, p == 150, every batch NORMAL / TEXTURE / PHONG → k_shade's FAST build
 constexpr uint32_t FD_FAST_SHADE = 0x100u;
+constexpr uint32_t N_WORK_LISTS = 16;
 constexpr uint32_t UNLISTED = 0xffffffffu; // tile_off of a tile whose list did not fit the record pool
 constexpr int MAX_TEX = 64;
 constexpr int MAX_MESH = 256;
@@ -116,9 +117,11 @@ struct RenderArgs {
   uint32_t *redo_list;           // tiles (frame * tiles_per_frame + tile) the FAST build of k_shade hands to the generic one
   uint32_t *redo_count;
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
-  uint32_t *worklist;            // [frame][tiles per frame]: tiles (lb*tiles_x + tx) that have an owner, in arrival order
-  uint32_t *work_count;          // [frame * CNT_STRIDE] entries in the frame's list (zeroed by k_setup, bumped by k_raster)
-  uint32_t shade_split;          // k_shade: virtual workgroups ("lanes") per frame
+  // k_shade's work: N_WORK_LISTS lists [FAST / generic build][frame % 8] of the tiles that have an owner, as
+  // frame * tiles_per_frame + (lb*tiles_x + tx), in arrival order; work_cap entries each
+  uint32_t *worklist;
+  uint32_t *work_count;          // [list * CNT_STRIDE]: word 0 = entries (zeroed by k_setup, bumped by k_raster), word 1 = k_shade's cursor
+  uint32_t work_cap;
   uint32_t tiles_x, n_local_bands, n_frames;
   float *out;             // [frame][4][local_rows][width]
   uint64_t frame_stride;  // floats per frame in out = 4*local_rows*width

@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.work_count[blockIdx.y * CNT_STRIDE] = 0u; // this frame's work list starts empty
-  if (blockIdx.x == 0 && blockIdx.y == 0) {                              // so do the record pool and the slow list
+  if (blockIdx.x == 0 && blockIdx.y == 0) { // the work lists, k_shade's cursors into them, the record pool and the slow list start empty
+    if (threadIdx.x < N_WORK_LISTS) a.work_count[threadIdx.x * CNT_STRIDE] = 0u, a.work_count[threadIdx.x * CNT_STRIDE + 1] = 0u;
     if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x * CNT_STRIDE] = 0u;
     if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
   }
@@ -559,6 +559,33 @@ __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz
   o1 = kdg * fmaf_(K.ka[1], I1, fmaf_(d1 * kdg, cosA, (d1 * K.ks[1]) * cosT));
   o2 = kdb * fmaf_(K.ka[2], I2, fmaf_(d2 * kdb, cosA, (d2 * K.ks[2]) * cosT));
 }
+// The same light in two steps: everything that does not involve the surface colour kd (attenuation, the two cosines, the
+// power), then the combination.  The FAST build runs step 1 for BOTH lights between issuing the texel load and using it, so
+// the load's latency passes under ~200 instructions instead of ~70 (same operations on the same operands: same bits).
+struct LightTerms {
+  float d0, d1, d2, cosA, cosT;
+};
+template <class M, bool L2P150>
+__device__ __forceinline__ void v_blinn_phong_terms(M &m, float nx, float ny, float nz, const FrameK &K, const SRZ_CAS srz_light *L,
+                                                    float px, float py, float pz, LightTerms &t) {
+  const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
+  float lx = Lx - px, ly = Ly - py, lz = Lz - pz;
+  float att = m.rsqrt2(fmaf_(lx, lx, ly * ly));
+  t.d0 = I0 * att, t.d1 = I1 * att, t.d2 = I2 * att;
+  float hx = lx + (K.eye[0] - px), hy = ly + (K.eye[1] - py), hz = lz + (K.eye[2] - pz);
+  v_normalized(m, hx, hy, hz);
+  float nlx = lx, nly = ly, nlz = lz;
+  v_normalized(m, nlx, nly, nlz);
+  t.cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
+  t.cosT = pow_frame<L2P150>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+}
+__device__ __forceinline__ void v_blinn_phong_combine(const FrameK &K, const SRZ_CAS srz_light *L, const LightTerms &t, float kdr,
+                                                      float kdg, float kdb, float &o0, float &o1, float &o2) {
+  const float I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
+  o0 = kdr * fmaf_(K.ka[0], I0, fmaf_(t.d0 * kdr, t.cosA, (t.d0 * K.ks[0]) * t.cosT));
+  o1 = kdg * fmaf_(K.ka[1], I1, fmaf_(t.d1 * kdg, t.cosA, (t.d1 * K.ks[1]) * t.cosT));
+  o2 = kdb * fmaf_(K.ka[2], I2, fmaf_(t.d2 * kdb, t.cosA, (t.d2 * K.ks[2]) * t.cosT));
+}
 
 // Shader::applyFragmentShader SIMD overload + simd_*_impl (src/Shader.cpp:128-386); colour out in [0,255]
 template <class M, int SH, bool L2P150>
@@ -571,19 +598,38 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
     c0 = (nx + 1.0f) * 0.5f, c1 = (ny + 1.0f) * 0.5f, c2 = (nz + 1.0f) * 0.5f;
   } else if (shader == SRZ_SHADER_TEXTURE || shader == SRZ_SHADER_PHONG) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
+    uint32_t texel = 0u;
     if (shader == SRZ_SHADER_TEXTURE) {
       float tw = (float)sd.tw, th = (float)sd.th;
       u = u * tw, v = v * th;
       u = sse_max(0.0f, sse_min(u, tw - 1.0f));
       v = sse_max(0.0f, sse_min(v, th - 1.0f));
       int32_t xi = cvt_rne_i32(u), yi = cvt_rne_i32(v);
-      uint32_t texel = sd.tex[(size_t)yi * sd.tw + xi];
-      const float inv255 = 1.0f / 255.0f;
-      kd0 = (float)(texel & 0xffu) * inv255, kd1 = (float)((texel >> 8) & 0xffu) * inv255,
-      kd2 = (float)((texel >> 16) & 0xffu) * inv255;
+      texel = sd.tex[(size_t)yi * sd.tw + xi];
     }
+    auto decode = [&]() {
+      if (shader == SRZ_SHADER_TEXTURE) {
+        const float inv255 = 1.0f / 255.0f;
+        kd0 = (float)(texel & 0xffu) * inv255, kd1 = (float)((texel >> 8) & 0xffu) * inv255,
+        kd2 = (float)((texel >> 16) & 0xffu) * inv255;
+      }
+    };
     c0 = c1 = c2 = 0.0f;
-    for (uint32_t l = 0; l < n_lights; ++l) { // (2 iterations known at compile time when L2P150: unrolled by the optimizer)
+    if constexpr (L2P150) { // both lights' colour-independent terms first, the texel only after them
+      LightTerms t0, t1;
+      v_blinn_phong_terms<M, true>(m, nx, ny, nz, K, K.lights, px, py, pz, t0);
+      v_blinn_phong_terms<M, true>(m, nx, ny, nz, K, K.lights + 1, px, py, pz, t1);
+      asm volatile("" : "+v"(t0.cosT), "+v"(t1.cosT), "+v"(texel)); // (keeps the decode below the terms)
+      decode();
+      float o0, o1, o2;
+      v_blinn_phong_combine(K, K.lights, t0, kd0, kd1, kd2, o0, o1, o2);
+      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+      v_blinn_phong_combine(K, K.lights + 1, t1, kd0, kd1, kd2, o0, o1, o2);
+      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+    } else {
+      decode();
+    }
+    for (uint32_t l = 0; l < (L2P150 ? 0u : n_lights); ++l) { // (2 iterations known at compile time when L2P150: unrolled by the optimizer)
       float o0, o1, o2;
       v_blinn_phong<M, L2P150>(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
@@ -634,6 +680,43 @@ __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, f
   o1 = ((K.ka[1] * I1 + (cosTheta * kd1) * d1) + (pw * K.ks[1]) * d1) * kd1;
   o2 = ((K.ka[2] * I2 + (cosTheta * kd2) * d2) + (pw * K.ks[2]) * d2) * kd2;
 }
+// the same light in two steps (see v_blinn_phong_terms): cosA = cosTheta, cosT = pow(cosAlpha, p)
+template <class M, bool L2P150>
+__device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
+                                                    const SRZ_CAS srz_light *L, LightTerms &t) {
+  const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
+  normalize3(m, nx, ny, nz);
+  float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
+  double dx = (double)(Lx - px), dy = (double)(Ly - py);
+  float dsq = (float)__builtin_sqrt(dx * dx + dy * dy);
+  m.div3(I0, I1, I2, dsq, t.d0, t.d1, t.d2);
+  float nlx = ldx, nly = ldy, nlz = ldz;
+  normalize3(m, nlx, nly, nlz);
+  t.cosA = std_max(0.0f, dot3(nx, ny, nz, nlx, nly, nlz));
+  float vx = K.eye[0] - px, vy = K.eye[1] - py, vz = K.eye[2] - pz;
+  float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
+  normalize3(m, hx, hy, hz);
+  float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
+  t.cosT = pow_frame<L2P150>(cosAlpha, K.p);
+}
+__device__ __forceinline__ void s_blinn_phong_combine(const FrameK &K, const SRZ_CAS srz_light *L, const LightTerms &t, float kd0,
+                                                      float kd1, float kd2, float &o0, float &o1, float &o2) {
+  const float I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
+  o0 = ((K.ka[0] * I0 + (t.cosA * kd0) * t.d0) + (t.cosT * K.ks[0]) * t.d0) * kd0;
+  o1 = ((K.ka[1] * I1 + (t.cosA * kd1) * t.d1) + (t.cosT * K.ks[1]) * t.d1) * kd1;
+  o2 = ((K.ka[2] * I2 + (t.cosA * kd2) * t.d2) + (t.cosT * K.ks[2]) * t.d2) * kd2;
+}
+// s_texel in two steps for the FAST build: the load from an address that is always inside the image (the reference's
+// out-of-range case — u or v == 1.0 → index == size → black — becomes a select afterwards), so it is not inside a branch
+// and can stay in flight across the lights' terms
+__device__ __forceinline__ uint32_t s_texel_issue(const ShadeDesc &sd, float u, float v, bool &inside) {
+  float cu = std_clamp(u, 0.0f, 1.0f), cv = std_clamp(v, 0.0f, 1.0f);
+  float fx = cu * (float)sd.tw, fy = cv * (float)sd.th;
+  int x = (int)fx, y = (int)fy;
+  inside = !(x < 0 || x >= sd.tw || y < 0 || y >= sd.th);
+  const int xs = min(max(x, 0), sd.tw - 1), ys = min(max(y, 0), sd.th - 1);
+  return sd.tex[(size_t)ys * sd.tw + xs];
+}
 
 // calcBumpMapping / calcDisplacementMapping common part (src/Shader.cpp:447-507)
 template <class M>
@@ -668,6 +751,25 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
   } else if (shader >= SRZ_SHADER_TEXTURE && shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
     float sx = px, sy = py, sz = pz, snx = nx, sny = ny, snz = nz;
+    if constexpr (L2P150 && (SH == SRZ_SHADER_TEXTURE || SH == SRZ_SHADER_PHONG)) {
+      // FAST build: texel load issued first, both lights' colour-independent terms, then the texel and the combination
+      bool inside = true;
+      uint32_t texel = 0u;
+      if (SH == SRZ_SHADER_TEXTURE) texel = s_texel_issue(sd, u, v, inside);
+      LightTerms t0, t1;
+      s_blinn_phong_terms<M, true>(m, K, sx, sy, sz, snx, sny, snz, K.lights, t0);
+      s_blinn_phong_terms<M, true>(m, K, sx, sy, sz, snx, sny, snz, K.lights + 1, t1);
+      asm volatile("" : "+v"(t0.cosT), "+v"(t1.cosT), "+v"(texel));
+      if (SH == SRZ_SHADER_TEXTURE) {
+        kd0 = m.div255((float)(texel & 0xffu)), kd1 = m.div255((float)((texel >> 8) & 0xffu)), kd2 = m.div255((float)((texel >> 16) & 0xffu));
+        if (!inside) kd0 = kd1 = kd2 = 0.0f;
+      }
+      float o0, o1, o2;
+      s_blinn_phong_combine(K, K.lights, t0, kd0, kd1, kd2, o0, o1, o2);
+      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+      s_blinn_phong_combine(K, K.lights + 1, t1, kd0, kd1, kd2, o0, o1, o2);
+      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+    } else {
     if (shader != SRZ_SHADER_PHONG) s_texel(m, sd, u, v, kd0, kd1, kd2);
     if (shader == SRZ_SHADER_BUMP) {
       float on;
@@ -682,12 +784,23 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
       s_blinn_phong<M, L2P150>(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
+    }
   }
   float q0 = std_clamp(c0, 0.0f, 1.0f) * 255.0f, q1 = std_clamp(c1, 0.0f, 1.0f) * 255.0f,
         q2 = std_clamp(c2, 0.0f, 1.0f) * 255.0f;
   r0 = (q0 == q0) ? (float)(uint32_t)q0 : 0.0f;
   r1 = (q1 == q1) ? (float)(uint32_t)q1 : 0.0f;
   r2 = (q2 == q2) ? (float)(uint32_t)q2 : 0.0f;
+}
+
+// A tile that has an owner goes to one of 16 work lists for k_shade: [build that shades the frame: FAST / generic][frame % 8]
+// (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so every list
+// comes out (roughly) frame by frame.
+__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry) {
+  // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
+  const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u) ? 0u : 1u;
+  const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
+  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = entry;
 }
 
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
@@ -1124,7 +1237,7 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
     }
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
-  if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame * CNT_STRIDE], 1u)] = tile;
+  if (tile_has_owner && lane == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile);
 }
 
 // ================================================================================================================
@@ -1328,7 +1441,7 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         }
       }
     }
-    if (tile_has_owner && lane == 0) a.worklist[(size_t)frame * tiles_per_frame + atomicAdd(&a.work_count[frame * CNT_STRIDE], 1u)] = tile;
+    if (tile_has_owner && lane == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile);
     __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
   }
   if (STATS) {
@@ -1603,36 +1716,34 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
 #undef SRZ_ST
       }
     }
-    __syncthreads(); // LDS is reused by the next tile of this persistent workgroup
   };
 
-  // The persistent grid walks VIRTUAL workgroups v = (group of 8 frames, lane j, frame within the group): v shades every
-  // S-th entry of its frame's work list from entry j.  Frame-in-group is the fastest index, so physical workgroup b
-  // (on XCD b % 8) shades frame f with f % 8 == b % 8 — the XCD that rasterised it, whose L2 holds its z / owner ids —
-  // and the ~1000 resident workgroups cover only a group or two of frames at a time (triangles + ids stay L2-resident;
-  // dealing v over ALL frames at once thrashes L2: +10 % kernel time; dropping the XCD affinity: +5..12 %).
-  const uint32_t F = a.n_frames, S = a.shade_split;
-  const uint32_t gsz = F < 8u ? F : 8u; // (fewer than 8 frames: every XCD works on all of them)
-  const uint32_t n_virtual = ((F + gsz - 1u) / gsz) * gsz * S;
-  for (uint32_t v = blockIdx.x; v < ((FAST || a.force_generic || a.any_generic) ? n_virtual : 0u); v += gridDim.x) {
-    const uint32_t r = v % (gsz * S), f = (v / (gsz * S)) * gsz + r % gsz, j = r / gsz;
-    if (f >= F) continue;
-    const bool frame_fast = !a.force_generic && ((as_const(a.frames) + f)->flags & FD_FAST_SHADE) != 0u;
-    if (frame_fast != FAST) continue; // the other build's frame
-    const uint32_t n_work = as_const(a.work_count)[f * CNT_STRIDE];
-    for (uint32_t w = j; w < n_work; w += S) {
-      const uint32_t e = as_const(a.worklist)[(size_t)f * tpf + w];
-      if constexpr (FAST)
-        shade_tile(f, e, std::integral_constant<int, 0>{});
-      else
-        shade_tile(f, e, std::integral_constant<int, 1>{});
-    }
+  // Workgroup b (on XCD b % 8) shades entries b/8, b/8 + G/8, ... of work list [this build][b % 8]: the tiles of the frames
+  // that XCD rasterised (its L2 holds their z / owner ids), in frame order.  The grid is LARGE (a tile or two per workgroup),
+  // so the hardware dispatcher hands the work out in order and at tile granularity: all resident workgroups are on the same
+  // few frames at any time (triangles + ids stay cache-resident), a CU slowed by the clear's waves simply receives fewer
+  // workgroups, the kernel's tail is a tile long — and, unlike a persistent grid, CU slots keep turning over, which lets the
+  // kernels of another stream (LaneRenderer: the next batch's k_bin / k_raster) in beside this one.  Measured on MI355X, 256
+  // frames of 1024^2: a persistent grid of 4096 workgroups dealing every 128th tile of a frame 0.78 ms (one stream), a
+  // persistent grid drawing tiles from atomic cursors the same on one stream but 7 % slower on two (it holds every CU slot to
+  // its end), this walk 0.73 ms.
+  const uint32_t L = (FAST ? 0u : 8u) + (blockIdx.x & 7u);
+  const uint32_t n_work = (FAST || a.force_generic || a.any_generic) ? as_const(a.work_count)[L * CNT_STRIDE] : 0u;
+  const SRZ_CAS uint32_t *list = as_const(a.worklist) + (size_t)L * a.work_cap;
+  for (uint32_t w = blockIdx.x >> 3; w < n_work; w += gridDim.x >> 3) {
+    const uint32_t x = list[w];
+    if constexpr (FAST)
+      shade_tile(x / tpf, x % tpf, std::integral_constant<int, 0>{});
+    else
+      shade_tile(x / tpf, x % tpf, std::integral_constant<int, 1>{});
+    __syncthreads(); // LDS is reused by the next tile
   }
   if constexpr (!FAST) { // the tiles the FAST build handed back (it ran before this kernel on the same stream)
     const uint32_t n_redo = *as_const(a.redo_count);
     for (uint32_t i = blockIdx.x; i < n_redo; i += gridDim.x) {
       const uint32_t x = as_const(a.redo_list)[i];
       shade_tile(x / tpf, x % tpf, std::integral_constant<int, 2>{});
+      __syncthreads(); // LDS is reused by the next tile
     }
   }
   if (STATS) {
@@ -1826,7 +1937,9 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s) {
   if (max_tiles == 0) return;
-  dim3 grid(max_tiles < 4096u ? max_tiles : 4096u); // persistent: workgroups stride over the worklists
+  static const uint32_t env_grid = getenv("SRZ_SHADE_GRID") ? (uint32_t)atoi(getenv("SRZ_SHADE_GRID")) : 0u;
+  const uint32_t gcap = env_grid ? env_grid : 16384u;
+  dim3 grid((std::min(max_tiles, gcap) + 7u) & ~7u); // (a multiple of 8: workgroup b serves list b % 8)
   if (stats) { // (counting runs shade every frame with the generic build: force_generic)
     hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), 0, s, a);
     return;

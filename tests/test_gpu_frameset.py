@@ -297,7 +297,7 @@ def test_lane_renderer_equals_one_frameset_and_timing_samples():
         ctx.set_kernel_timing(0)
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
         assert len(samples) == 3 * lanes == kt["launches"] and all(x > 0 for x in samples)
-        assert max(samples) <= span * 1.001 and span <= sum(samples) * 1.5
+        assert max(samples) <= span * 1.001
         assert kt["bin_ms"] == 0 and abs(kt["total_ms"] - sum(samples) / len(samples)) < 1e-3
         st = lr.stats()  # (the texture term of the algorithmic bytes needs the counters)
         assert st == fs.stats()
