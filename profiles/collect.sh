@@ -8,12 +8,12 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+CMD="python3 bench.py --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_traced.json 2> $OUT/trace.log || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log || exit 1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.log || exit 1
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench_plain.json 2> $OUT/bench_plain.log || exit 1
+python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.log || exit 1
 # the other BASELINE configs: kernel-trace stats + SQ counters of the dev probe (whole frames on one GPU)
 for c in "3 64" "4 32" "5 16"; do
   n=${c%% *}
