@@ -304,3 +304,35 @@ def test_lane_renderer_equals_one_frameset_and_timing_samples():
         assert lr.algorithmic_bytes() == fs.algorithmic_bytes()
         lr.close()
     fs.close()
+
+
+@pytest.mark.parametrize("n_frames", [3, 8, 19])
+def test_mixed_fast_and_generic_frames_share_one_set(orc, n_frames):
+    """k_shade's two builds take their tiles from different work lists of the same render: frames the FAST build may shade
+    (2 lights, p = 150, NORMAL / TEXTURE / PHONG) interleaved with frames only the generic one can (3 lights, another
+    exponent, an empty frame), at frame counts below, at and above the 8 lists' period — every frame bit-identical to the
+    oracle's"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    three = np.concatenate([scenes.LIGHTS, np.array([[[-0.7, 0.2, 0.8], [30, 40, 50]]], np.float32)])
+    frames = []
+    for i in range(n_frames):
+        base = scenes.config2(i, size=256, shader=(abi.SHADER_TEXTURE, abi.SHADER_PHONG, abi.SHADER_NORMAL)[i % 3])
+        tris = base.tris[0]
+        if i % 4 == 1:      # generic: three lights
+            frames.append(abi.Frame(256, 256, scenes.EYE, three, [(abi.SHADER_TEXTURE, scenes.TEX_SPOT, tris)], abi.FUSED_CLEAR))
+        elif i % 4 == 3:    # generic: another exponent
+            frames.append(abi.Frame(256, 256, scenes.EYE, scenes.LIGHTS, [(abi.SHADER_PHONG, -1, tris)], abi.FUSED_CLEAR, p=8.0))
+        elif i == 4:        # nothing to draw: every tile is the fused clear's
+            frames.append(abi.Frame(256, 256, scenes.EYE, scenes.LIGHTS, [(abi.SHADER_NORMAL, -1, tris[:0])], abi.FUSED_CLEAR))
+        else:
+            frames.append(base)
+    fs, out = render(ctx, frames)
+    got = out.cpu().numpy()
+    for i, f in enumerate(frames):
+        rc, ref, st = orc.draw(f)
+        for p in range(4):
+            assert np.array_equal(bits(got[i, p]), bits(ref[p])), (n_frames, i, p)
+    fs.close()
+    ctx.close()
