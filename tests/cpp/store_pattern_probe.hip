@@ -21,6 +21,25 @@ __global__ __launch_bounds__(256) void k_rows(float *out, int n_items) { // item
       for (int pl = 0; pl < 4; ++pl) st(base + (size_t)pl * W * H + (size_t)ly * W + threadIdx.x * 4, v);
   }
 }
+__global__ __launch_bounds__(256) void k_rows_pm(float *out, int n_items) { // the same bytes, plane after plane within the band
+  const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int f = it / (H / 32), b = it % (H / 32);
+    float *base = out + (size_t)f * 4 * W * H + (size_t)b * 32 * W;
+    for (int pl = 0; pl < 4; ++pl)
+      for (int ly = 0; ly < 32; ++ly) st(base + (size_t)pl * W * H + (size_t)ly * W + threadIdx.x * 4, v);
+  }
+}
+__global__ __launch_bounds__(256) void k_flat(float *out, size_t n16) { // a flat fill: consecutive 16-byte units, grid-stride
+  const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) st(out + i * 4, v);
+}
+__global__ __launch_bounds__(256) void k_flat_chunk(float *out, size_t n16) { // flat fill, each workgroup a contiguous 128 KiB run at a time
+  const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+  const size_t chunks = n16 / 8192;
+  for (size_t c = blockIdx.x; c < chunks; c += gridDim.x)
+    for (int k = 0; k < 32; ++k) st(out + (c * 8192 + k * 256 + threadIdx.x) * 4, v);
+}
 template <int TW> // tile = 32 rows x TW pixels; 256 threads: each stores 16 B; a row of the tile = TW*4 bytes
 __global__ __launch_bounds__(256) void k_tiles(float *out, int n_items, int planes) {
   const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -55,6 +74,15 @@ int main() {
     char nm[64];
     snprintf(nm, sizeof nm, "rows  grid %d", grid);
     run(nm, [&] { hipLaunchKernelGGL(k_rows, dim3(grid), dim3(256), 0, 0, d, F * (H / 32)); }, gb);
+  }
+  for (int grid : {64, 2048}) {
+    char nm[64];
+    snprintf(nm, sizeof nm, "rows plane-major grid %d", grid);
+    run(nm, [&] { hipLaunchKernelGGL(k_rows_pm, dim3(grid), dim3(256), 0, 0, d, F * (H / 32)); }, gb);
+    snprintf(nm, sizeof nm, "flat grid-stride grid %d", grid);
+    run(nm, [&] { hipLaunchKernelGGL(k_flat, dim3(grid), dim3(256), 0, 0, d, bytes / 16); }, gb);
+    snprintf(nm, sizeof nm, "flat 128K runs grid %d", grid);
+    run(nm, [&] { hipLaunchKernelGGL(k_flat_chunk, dim3(grid), dim3(256), 0, 0, d, bytes / 16); }, gb);
   }
   for (int grid : {1280, 16384}) {
     char nm[64];
