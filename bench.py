@@ -345,7 +345,7 @@ def main():
             pipe.step()
         pipe.drain()
         fence()
-        ctx.set_kernel_timing(1)
+        ctx.set_kernel_timing(2)  # (per-kernel split: the exchange dominates an N > 1 step, two more events do not matter)
         ctx.kernel_time_ms(reset=True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
