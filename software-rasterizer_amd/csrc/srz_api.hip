@@ -92,13 +92,11 @@ struct srz_frameset {
   BatchDesc *d_batches = nullptr;
   srz_light *d_lights = nullptr;
   // per-tile triangle lists: records in a pool of n_sub sub-pools (srz_device.h, RenderArgs); every render reports what
-  // it asked of each sub-pool (h_pool_heads, copied back asynchronously), and a render that finds the previous demand
+  // it asked of each sub-pool (h_pool_heads: mapped host memory the device stores into), and a render that finds the previous demand
   // above the capacity grows the pool first — so the memory is O(triangle-tile pairs), not O(bands x triangles)
   RasterRec *d_pool = nullptr;
   uint32_t pool_sub_cap = 0, pool_n_sub = 1;
   uint32_t *d_pool_heads = nullptr, *h_pool_heads = nullptr;
-  hipEvent_t pool_ev = nullptr;
-  bool pool_pending = false;
   uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_slow_list = nullptr, *d_slow_count = nullptr;
   uint32_t *d_redo_list = nullptr; // (its counter is d_slow_count[1])
   bool any_fast = false, any_generic = true; // which builds of k_shade the frames need (classify_frames)
@@ -189,7 +187,6 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_pool);
   (void)hipFree(fs->d_pool_heads);
   if (fs->h_pool_heads) (void)hipHostFree(fs->h_pool_heads);
-  if (fs->pool_ev) (void)hipEventDestroy(fs->pool_ev);
   (void)hipFree(fs->d_tile_cnt);
   (void)hipFree(fs->d_tile_off);
   (void)hipFree(fs->d_slow_list);
@@ -215,6 +212,7 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.tex = ctx->d_tex;
   a.pool = fs->d_pool;
   a.pool_heads = fs->d_pool_heads;
+  a.pool_demand = fs->h_pool_heads; // (hipHostMallocMapped: the same address on the device)
   a.pool_sub_cap = fs->pool_sub_cap;
   a.pool_sub_mask = fs->pool_n_sub - 1u;
   a.tile_cnt = fs->d_tile_cnt;
@@ -307,12 +305,15 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipMemcpyAsync(fs->d_sdesc, h.data(), sizeof(ShadeDescG) * h.size(), hipMemcpyHostToDevice, s));
     fs->sdesc_version = ctx->tex_version;
   }
-  // the record pool follows what the previous render asked for (read back asynchronously): growing is rare and the one
-  // place where a render waits for the device
-  if (fs->pool_pending && hipEventQuery(fs->pool_ev) == hipSuccess) {
-    fs->pool_pending = false;
+  // the record pool follows what the previous renders asked for: growing is rare and the one place where a render waits
+  // for the device
+  { // (h_pool_heads is pinned host memory the rasteriser's first workgroup stores into: whatever it holds is a demand some
+    // finished or running render of this set really had — a stale value only delays the growth by a render)
     uint32_t need = 0;
-    for (uint32_t i = 0; i < fs->pool_n_sub; ++i) need = std::max(need, fs->h_pool_heads[i * CNT_STRIDE]);
+    for (uint32_t i = 0; i < fs->pool_n_sub; ++i) {
+      const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[i];
+      if (v > need) need = v;
+    }
     if (need > fs->pool_sub_cap) {
       HIP_TRY(ctx, hipDeviceSynchronize());
       const uint64_t cap = (uint64_t)need + need / 4u + 64u;
@@ -350,14 +351,6 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
   launch_bin(a, fs->n_frames, fs->max_tris, s);
-  // what this render asked of the record pool goes back to the host (read by the NEXT render): on the side stream behind the
-  // clear when there is one — a copy in the launch stream here would sit between k_bin and k_raster (≈15 µs)
-  auto read_back_demand = [&](hipStream_t cs) {
-    HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, cs));
-    HIP_TRY(ctx, hipEventRecord(fs->pool_ev, cs));
-    fs->pool_pending = true;
-    return (int)SRZ_OK;
-  };
   if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in line (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
@@ -384,7 +377,6 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
     launch_clear(a, fs->max_tiles, true, side_s);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
-    if (int rc = read_back_demand(side_s)) return rc; // (after the join event: not on the render's critical path)
   } else if (any_fused) {
     launch_clear(a, fs->max_tiles, false, s);
   }
@@ -396,7 +388,6 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, fs->any_fast, fs->any_generic, s);
   if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
-  else if (int rc = read_back_demand(s)) return rc;
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -635,8 +626,10 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     fs->pool_sub_cap = (uint32_t)cap;
     FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(RasterRec) * cap * n_sub));
     FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64)); // (one cache line per allocator)
-    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64, hipHostMallocDefault));
-    FS_TRY(hipEventCreateWithFlags(&fs->pool_ev, hipEventDisableTiming));
+    // what a render asked of each sub-pool comes back through pinned, device-mapped host memory (k_raster's first workgroup
+    // stores it there): no copy, no event and no query on the launch path
+    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * 64);
     FS_TRY(dev_alloc((void **)&fs->d_tile_cnt, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_tile_off, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));

@@ -106,6 +106,7 @@ struct RenderArgs {
   // rasterised by k_raster_slow straight from the frame's stream, and the host grows the pool before the next render.
   RasterRec *pool;
   uint32_t *pool_heads;          // [n_sub] records requested from each sub-pool by this render (zeroed by k_setup)
+  uint32_t *pool_demand;         // [n_sub] pinned host memory: pool_heads as this render left them (stored by k_raster's first workgroup)
   uint32_t pool_sub_cap, pool_sub_mask;
   uint32_t *tile_cnt;            // [frame][local band][tiles_x] entries in the tile's list (0: k_clear's tile)
   uint32_t *tile_off;            // [frame][local band][tiles_x] first record in pool[], or UNLISTED

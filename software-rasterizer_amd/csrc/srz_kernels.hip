@@ -952,6 +952,9 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   // renders frame (i % 8) of its group of 8 frames: the 8 XCDs walk the SAME tile sequence in lockstep (balanced by
   // construction), and all tiles of one frame — hence its tile lists — live in ONE XCD's L2.
   const uint32_t wg = blockIdx.x;
+  // what k_bin asked of the record pool (final: k_bin has finished) goes to the host through mapped pinned memory; the next
+  // render of this set reads it before it launches and grows the pool if a band did not fit
+  if (wg == 0 && (uint32_t)lane <= a.pool_sub_mask) a.pool_demand[lane] = a.pool_heads[lane * CNT_STRIDE];
   const uint32_t xcd = wg & 7u, j = wg >> 3;
   const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
   const uint32_t frame = (j / tiles_per_frame) * 8u + xcd, tile = j % tiles_per_frame;
