@@ -378,7 +378,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     launch_clear(a, fs->max_tiles, true, side_s);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
   } else if (any_fused) {
-    launch_clear(a, fs->max_tiles, false, s);
+    a.clear_in_raster = 1u; // (small job: the rasteriser's own waves clear the tiles no bbox reaches — one kernel less in line)
   }
   launch_raster(a, fs->n_frames, stats, s);
   if (turns) {

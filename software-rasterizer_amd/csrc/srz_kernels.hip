@@ -959,12 +959,36 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
   const uint32_t frame = (j / tiles_per_frame) * 8u + xcd, tile = j % tiles_per_frame;
   if (frame >= a.n_frames) return;
-  // nothing listed for this tile: nothing to rasterise, and its clear (if any) is k_clear's job
+  // nothing listed for this tile: nothing to rasterise; its clear (if any) is k_clear's job — or, in a small job that has
+  // no k_clear beside it (one kernel boundary less on the latency path), this wave's
   const uint32_t cnt = as_const(a.tile_cnt)[(size_t)frame * tiles_per_frame + tile];
-  if (cnt == 0u) return;
-  const uint32_t off = as_const(a.tile_off)[(size_t)frame * tiles_per_frame + tile];
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
   const uint32_t flags = fd->flags | a.flags_or;
+  if (cnt == 0u) {
+    if (a.clear_in_raster && (flags & SRZ_FUSED_CLEAR)) {
+      const int W = fd->width, H = fd->height;
+      const uint32_t lb = tile / a.tiles_x;
+      const int tx0 = (int)(tile % a.tiles_x) * TILE, ty0 = ((int)lb * a.shard_world + a.shard_rank) * BAND;
+      const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
+      const size_t plane = (size_t)a.local_rows * (size_t)W;
+      float *out0 = a.out + (size_t)frame * a.frame_stride + (size_t)lb * BAND * (size_t)W;
+      const float inf = __builtin_inff();
+      const float4 inf4 = make_float4(inf, inf, inf, inf), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int ly = it * 8 + (lane >> 3), x4 = tx0 + (lane & 7) * 4;
+        if (ty0 + ly > ty1 || x4 > tx1) continue;
+        float *gz = out0 + (size_t)ly * W + x4;
+        if (((W & 3) == 0) && x4 + 3 <= tx1) {
+          store_nt(gz, inf4), store_nt(gz + plane, zero4), store_nt(gz + 2 * plane, zero4), store_nt(gz + 3 * plane, zero4);
+        } else {
+          for (int k = 0; k < 4 && x4 + k <= tx1; ++k) gz[k] = inf, gz[plane + k] = 0.f, gz[2 * plane + k] = 0.f, gz[3 * plane + k] = 0.f;
+        }
+      }
+    }
+    return;
+  }
+  const uint32_t off = as_const(a.tile_off)[(size_t)frame * tiles_per_frame + tile];
   if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
     if (lane == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
