@@ -336,3 +336,30 @@ def test_mixed_fast_and_generic_frames_share_one_set(orc, n_frames):
             assert np.array_equal(bits(got[i, p]), bits(ref[p])), (n_frames, i, p)
     fs.close()
     ctx.close()
+
+
+def test_two_lanes_at_batch_size_take_turns_and_match_the_oracle(orc):
+    """two lanes of 8 frames of 1024^2 each (8192 tiles per lane: the side-stream clear and the raster turns between streams
+    are both active), four batches back to back into rotating outputs: every frame of every batch is the oracle's"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    frames = [scenes.config2(i) for i in range(16)]
+    lr = parallel.LaneRenderer(ctx, frames, 2)
+    assert lr.cuts == [0, 8, 16]
+    outs = [torch.full(lr.out_shape, float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)]
+    for k in range(4):
+        lr.render(outs[k % 2].data_ptr(), abi.FUSED_CLEAR)
+    lr.synchronize()
+    ref = {}
+    for i in (0, 5, 8, 15):
+        rc, planes, st = orc.draw(frames[i])
+        ref[i] = planes
+    for o in outs:
+        got = o.cpu().numpy()
+        for i, planes in ref.items():
+            for p in range(4):
+                assert np.array_equal(bits(got[i, p]), bits(planes[p])), (i, p)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    lr.close()
+    ctx.close()
