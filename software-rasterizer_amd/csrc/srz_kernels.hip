@@ -943,10 +943,25 @@ __device__ __forceinline__ float bperm_f(int addr, float v) {
 }
 __device__ __forceinline__ uint32_t bperm_u(int addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v); }
 
-__global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
+// WAVES = 1: the throughput build (batches: thousands of tiles in flight, one wave each).  WAVES = 4: the latency build for
+// jobs of a few frames, where a frame is as slow as its heaviest tile — the four waves of a tile share its keys (the LDS
+// minimum is atomic across waves), each loads the chunk's records and takes every fourth batch of 64 items and a quarter of
+// the init / decode / write-out rows.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(RenderArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long s_key[TILE * KEY_STRIDE];
+  __shared__ uint32_t s_mark_x[WAVES > 1 ? WAVES * 64 : 1]; // WAVES > 1: the item marks of each wave (one wave: the keys' pad column)
+  __shared__ uint32_t s_wg[WAVES > 1 ? 3 : 1];              // WAVES > 1: redo / owner flags of the tile, the farthest depth
+  constexpr int ITS = 4 / WAVES;                            // 8-row strips of the tile per wave in the row-wise phases
 
   const int lane = threadIdx.x & 63;
+  const int wave = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  auto wg_barrier = [] {
+    if constexpr (WAVES > 1)
+      __syncthreads();
+    else
+      __builtin_amdgcn_wave_barrier();
+  };
   // XCD-aware tile assignment.  Workgroups are dealt round-robin to the 8 XCDs in launch order, and launch order is
   // strict: one XCD whose slots are full of long tiles stalls the dispatch of everything behind it.  So workgroup i
   // renders frame (i % 8) of its group of 8 frames: the 8 XCDs walk the SAME tile sequence in lockstep (balanced by
@@ -954,7 +969,7 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   const uint32_t wg = blockIdx.x;
   // what k_bin asked of the record pool (final: k_bin has finished) goes to the host through mapped pinned memory; the next
   // render of this set reads it before it launches and grows the pool if a band did not fit
-  if (wg == 0 && (uint32_t)lane <= a.pool_sub_mask) a.pool_demand[lane] = a.pool_heads[lane * CNT_STRIDE];
+  if (wg == 0 && wave == 0 && (uint32_t)lane <= a.pool_sub_mask) a.pool_demand[lane] = a.pool_heads[lane * CNT_STRIDE];
   const uint32_t xcd = wg & 7u, j = wg >> 3;
   const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
   const uint32_t frame = (j / tiles_per_frame) * 8u + xcd, tile = j % tiles_per_frame;
@@ -975,7 +990,8 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
       const float inf = __builtin_inff();
       const float4 inf4 = make_float4(inf, inf, inf, inf), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int k = 0; k < ITS; ++k) {
+        const int it = wave * ITS + k;
         const int ly = it * 8 + (lane >> 3), x4 = tx0 + (lane & 7) * 4;
         if (ty0 + ly > ty1 || x4 > tx1) continue;
         float *gz = out0 + (size_t)ly * W + x4;
@@ -990,7 +1006,7 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   }
   const uint32_t off = as_const(a.tile_off)[(size_t)frame * tiles_per_frame + tile];
   if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
-    if (lane == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
+    if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
   }
   const uint32_t lb = tile / a.tiles_x;
@@ -1005,7 +1021,7 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
 
   // ---- phase A: tile init (fused clear → +inf, else the in/out z plane) with the incoming-depth tie-break ----------
-  for (int i = lane; i < TILE * TILE; i += 64) {
+  for (int i = (int)threadIdx.x; i < TILE * TILE; i += 64 * WAVES) {
     const int ly = i >> 5, lx = i & 31;
     float z = __builtin_inff();
     if (!fused && tx0 + lx <= tx1 && ty0 + ly <= ty1) z = out0[(size_t)ly * W + tx0 + lx];
@@ -1015,11 +1031,12 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
   // the pad key of every row is scratch: 64 dword marks, mark r in row r / 2
   // (plain LDS accesses: the mark a triangle writes may be the one this lane reads, so the compiler keeps their order;
   // `volatile` would turn them into flat, system-scope accesses)
-  uint32_t *const s_mark = reinterpret_cast<uint32_t *>(s_key);
-  auto mark_at = [](uint32_t r) { return ((r >> 1) * (uint32_t)KEY_STRIDE + TILE) * 2u + (r & 1u); };
+  uint32_t *const s_mark = WAVES > 1 ? s_mark_x + wave * 64 : reinterpret_cast<uint32_t *>(s_key);
+  auto mark_at = [](uint32_t r) { return WAVES > 1 ? r : ((r >> 1) * (uint32_t)KEY_STRIDE + TILE) * 2u + (r & 1u); };
   const uint32_t my_mark = mark_at((uint32_t)lane);
   s_mark[my_mark] = 0u;
-  __builtin_amdgcn_wave_barrier();
+  if (WAVES > 1 && threadIdx.x < 3) s_wg[threadIdx.x] = 0u;
+  wg_barrier();
 
   // ---- phase B: the tile's list, 64 records at a time --------------------------------------------------------------
   // geometry of one record's bbox ∩ tile in TILE-LOCAL coordinates: V columns [x0, v-1] in nseg pieces of 8, S columns [v, x1]
@@ -1101,7 +1118,11 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
 
     // ---- V items: 8 pixels of one row each (barycentric(__m256) + inside mask + z, src/Rasterizer.cpp:89-127,310-334)
     uint32_t carry = 0;
-    for (uint32_t P0 = 0; P0 < TV; P0 += 64) {
+    for (uint32_t P0 = 64u * (uint32_t)wave; P0 < TV; P0 += 64u * WAVES) {
+      if constexpr (WAVES > 1) { // (this wave did not run the batch before: the triangle that reaches into this one is the last to start before it)
+        const unsigned long long before = __ballot(nV != 0u && (offs & 0xffffu) < P0);
+        carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+      }
       const uint32_t r = (offs & 0xffffu) - P0;
       if (nV != 0u && r < 64u) s_mark[mark_at(r)] = (uint32_t)lane + 1u;
       __builtin_amdgcn_wave_barrier();
@@ -1149,7 +1170,11 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
     }
     // ---- S items: one pixel each (insideTriangle + barycentric(scalar) + z, src/Rasterizer.cpp:11-70,465-477) --------
     carry = 0;
-    for (uint32_t P0 = 0; P0 < TS; P0 += 64) {
+    for (uint32_t P0 = 64u * (uint32_t)wave; P0 < TS; P0 += 64u * WAVES) {
+      if constexpr (WAVES > 1) {
+        const unsigned long long before = __ballot(nS != 0u && (offs >> 16) < P0);
+        carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+      }
       const uint32_t r = (offs >> 16) - P0;
       if (nS != 0u && r < 64u) s_mark[mark_at(r)] = (uint32_t)lane + 1u;
       __builtin_amdgcn_wave_barrier();
@@ -1184,27 +1209,30 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
     // the tile's farthest depth after this group (pixels outside the frame keep +inf: no dropping there); also between the
     // chunks of a long list once dropping has started paying
     if (gi + 1 < n_groups || (n_groups > 1 && base + 64 < cnt)) {
-      __builtin_amdgcn_wave_barrier();
+      wg_barrier(); // (every wave's minima of this group are in the keys)
       uint32_t zm = 0;
 #pragma unroll
       for (int it = 0; it < 16; ++it) zm = max(zm, (uint32_t)(s_key[(it * 2 + (lane >> 5)) * KEY_STRIDE + (lane & 31)] >> 32));
       for (int o = 32; o > 0; o >>= 1) zm = max(zm, (uint32_t)__shfl_xor((int)zm, o));
       zfar = zm;
+      // (the waves must agree on the bound: it decides the item counts, hence which items a batch holds — no wave may lower a
+      // key before all have read them)
+      wg_barrier();
     }
     } // groups
   } // chunks
-  __builtin_amdgcn_wave_barrier();
+  wg_barrier();
 
   // ---- phase C: decode the keys, write out ------------------------------------------------------------------------
   //  some final key needs the ordered algorithm  : the tile goes to k_raster_slow, nothing is written here
   //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
   //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
-  float4 z4[4];
-  uint4 id4[4];
+  float4 z4[ITS];
+  uint4 id4[ITS];
   bool any_owner = false, redo = false;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+  for (int it = 0; it < ITS; ++it) {
+    const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const unsigned long long *kr = &s_key[ly * KEY_STRIDE + lx4]; // (rows are 264 bytes apart: 8-byte aligned reads)
     const unsigned long long k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
     const uint32_t tb[4] = {(uint32_t)k0, (uint32_t)k1, (uint32_t)k2, (uint32_t)k3};
@@ -1221,18 +1249,24 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
     z4[it] = make_float4(zz[0], zz[1], zz[2], zz[3]);
     id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
   }
-  if (__ballot(redo) != 0ull) {
-    if (lane == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
+  bool tile_redo = __ballot(redo) != 0ull, tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
+  if constexpr (WAVES > 1) { // tile-wide: through LDS
+    if (lane == 0 && tile_redo) s_wg[0] = 1u;
+    if (lane == 0 && tile_has_owner) s_wg[1] = 1u;
+    __syncthreads();
+    tile_redo = s_wg[0] != 0u, tile_has_owner = s_wg[1] != 0u;
+  }
+  if (tile_redo) {
+    if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
   }
-  const bool tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
   const bool vec_ok = (W & 3) == 0;
   if (tile_has_owner || fused) {
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+    for (int it = 0; it < ITS; ++it) {
+      const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
       const int y = ty0 + ly, x4 = tx0 + lx4;
       if (y > ty1 || x4 > tx1) continue;
       float *gz = out0 + (size_t)ly * W + x4;
@@ -1264,7 +1298,7 @@ __global__ __launch_bounds__(64, 5) void k_raster(RenderArgs a) {
     }
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
-  if (tile_has_owner && lane == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile);
+  if (tile_has_owner && lane == 0 && wave == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile);
 }
 
 // ================================================================================================================
@@ -1945,7 +1979,8 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
   if (n_frames <= 0 || a.n_local_bands == 0) return;
   const uint32_t groups = ((uint32_t)n_frames + 7u) / 8u;
   static const int env = getenv("SRZ_BIN_WAVES") ? atoi(getenv("SRZ_BIN_WAVES")) : 0;
-  const int waves = env ? env : (max_tris <= 32768u ? 4 : BIN_MAX_WAVES); // (measured: 4 waves best at 5.9 k triangles, 8 at 94 k)
+  // (measured: 4 waves best at 5.9 k triangles, 8 at 94 k; a job with fewer band workgroups than CUs is pure latency: 8)
+  const int waves = env ? env : ((max_tris <= 32768u && (uint32_t)n_frames * a.n_local_bands > 256u) ? 4 : BIN_MAX_WAVES);
   const size_t lds = sizeof(uint32_t) * (3u * (size_t)a.tiles_x + 128u * waves + 4u);
   hipLaunchKernelGGL(k_bin, dim3(groups * 8u * a.n_local_bands), dim3(64 * waves), lds, s, a);
 }
@@ -1984,13 +2019,17 @@ void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s)
   if (!once && getenv("SRZ_DEBUG")) {
     once = true;
     int nb = 0, ns = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raster, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raster<1>, 64, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, k_shade<false, true>, 256, 0);
     fprintf(stderr, "[srz] occupancy: k_raster %d waves/CU, k_shade %d WGs/CU\n", nb, ns);
   }
   const uint32_t groups = ((uint32_t)n_frames + 7u) / 8u;
   const uint32_t tiles = groups * 8u * a.n_local_bands * a.tiles_x;
-  hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(64), 0, s, a);
+  // a few frames: four waves per tile (the frame is as slow as its heaviest tile); batches: one wave per tile
+  if ((uint32_t)n_frames * a.n_local_bands * a.tiles_x <= 4096u)
+    hipLaunchKernelGGL(k_raster<4>, dim3(tiles), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_raster<1>, dim3(tiles), dim3(64), 0, s, a);
   // the ordered rasteriser for whatever k_raster listed (normally nothing: its waves read a zero and leave)
   const uint32_t slow_grid = (stats || a.force_ordered) ? (tiles < 4096u ? tiles : 4096u) : (tiles < 256u ? tiles : 256u);
   if (stats)
