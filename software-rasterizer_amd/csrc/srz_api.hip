@@ -311,7 +311,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     // finished or running render of this set really had — a stale value only delays the growth by a render)
     uint32_t need = 0;
     for (uint32_t i = 0; i < fs->pool_n_sub; ++i) {
-      const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[i];
+      const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[i * CNT_STRIDE];
       if (v > need) need = v;
     }
     if (need > fs->pool_sub_cap) {
@@ -357,6 +357,12 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
   const bool side = any_fused && fs->max_tiles >= 8192;
   unsigned ev = 0;
+  // the record pool's demand of this render → host (word 0 of every allocator's line).  No event: the next render reads
+  // whatever has arrived (see the growth check above).  The latency build of k_raster stores it itself.
+  auto copy_demand = [&](hipStream_t cs) {
+    HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, cs));
+    return (int)SRZ_OK;
+  };
   if (side) {
     if (!ctx->stream2) {
       // The clear must run BESIDE the launch stream, so it may not share a hardware queue with it: HIP deals its streams
@@ -377,6 +383,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
     launch_clear(a, fs->max_tiles, true, side_s);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
+    if (int rc = copy_demand(side_s)) return rc; // (behind the join: off the critical path)
   } else if (any_fused) {
     a.clear_in_raster = 1u; // (small job: the rasteriser's own waves clear the tiles no bbox reaches — one kernel less in line)
   }
@@ -388,6 +395,8 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
   launch_shade(a, fs->max_tiles, stats, fs->any_fast, fs->any_generic, s);
   if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
+  else if (!raster_four_waves(a))
+    if (int rc = copy_demand(s)) return rc;
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -626,10 +635,10 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     fs->pool_sub_cap = (uint32_t)cap;
     FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(RasterRec) * cap * n_sub));
     FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64)); // (one cache line per allocator)
-    // what a render asked of each sub-pool comes back through pinned, device-mapped host memory (k_raster's first workgroup
-    // stores it there): no copy, no event and no query on the launch path
-    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * 64, hipHostMallocMapped | hipHostMallocCoherent));
-    if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * 64);
+    // what a render asked of each sub-pool comes back through pinned, device-mapped host memory: small jobs store it from
+    // k_raster's first workgroup (no copy, no event, no query on the launch path), batches copy it on the clear's side stream
+    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * 64);
     FS_TRY(dev_alloc((void **)&fs->d_tile_cnt, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_tile_off, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));

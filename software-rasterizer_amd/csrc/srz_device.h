@@ -106,7 +106,7 @@ struct RenderArgs {
   // rasterised by k_raster_slow straight from the frame's stream, and the host grows the pool before the next render.
   RasterRec *pool;
   uint32_t *pool_heads;          // [n_sub] records requested from each sub-pool by this render (zeroed by k_setup)
-  uint32_t *pool_demand;         // [n_sub] pinned host memory: pool_heads as this render left them (stored by k_raster's first workgroup)
+  uint32_t *pool_demand;         // pinned host memory laid out like pool_heads: what this render asked of each sub-pool (latency build of k_raster)
   uint32_t pool_sub_cap, pool_sub_mask;
   uint32_t *tile_cnt;            // [frame][local band][tiles_x] entries in the tile's list (0: k_clear's tile)
   uint32_t *tile_off;            // [frame][local band][tiles_x] first record in pool[], or UNLISTED
@@ -138,6 +138,7 @@ void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, 
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
 void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);
+bool raster_four_waves(const RenderArgs &a); // the latency build of k_raster serves this job (it also reports the pool's demand)
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
