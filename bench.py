@@ -163,20 +163,8 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     torch, ctx, fs = case.torch, case.ctx, case.fs
     from srz import abi
     out = case.out[0]
-    calibration = None
-    if lanes <= 0:  # auto: a short untimed comparison of one stream against two lanes picks the layout of the timed region
-        calibration = {}
-        for n_l in (1, 2):
-            cand = case.lanes(n_l)
-            for _ in range(6):
-                cand.render(out.data_ptr(), abi.FUSED_CLEAR)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(12):
-                cand.render(out.data_ptr(), abi.FUSED_CLEAR)
-            fence()
-            calibration[n_l] = (time.perf_counter() - t0) / 12 * 1e3
-        lanes = min(calibration, key=calibration.get)
+    if lanes <= 0:  # auto: two lanes when each still holds a batch (measured: +4..8 % at >= 64 frames per step, -2 % at 32)
+        lanes = 2 if case.n_frames >= 64 else 1
     lr = case.lanes(lanes)
     for _ in range(warmup):
         lr.render(out.data_ptr(), abi.FUSED_CLEAR)
@@ -193,7 +181,6 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     n_l = len(lr.sets)
     per_step = [max(samples[i:i + n_l]) for i in range(0, len(samples) - n_l + 1, n_l)]  # a step ends with its slowest lane
     kt["lane_launch_ms"], kt["total_ms"], kt["lanes"] = kt["total_ms"], span_ms / max(steps, 1), n_l
-    kt["lanes_calibration_ms"] = calibration
     # ---- not part of the measurement: the same batch in ONE piece on ONE stream (whole-launch time, then the kernel split)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -235,7 +222,6 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
                      "lanes": kt.get("lanes", 1), "lane_launch_ms": kt.get("lane_launch_ms"),
-                     "lanes_calibration_ms_per_step": kt.get("lanes_calibration_ms"),
                      "one_stream": {"ms_per_step": kt.get("one_stream_ms_per_step"), "launch_ms": kt.get("split_total_ms"),
                                     "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]}},
     }
@@ -256,10 +242,10 @@ def main():
     ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
                     help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
                          "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
-    ap.add_argument("--lanes", type=int, default=1,
+    ap.add_argument("--lanes", type=int, default=0,
                     help="N=1: the batch is rendered as this many runs of whole frames on streams of their own "
-                         "(srz.parallel.LaneRenderer); 1 = one frameset on one stream; 0 = whichever of 1 and 2 a short "
-                         "untimed comparison before the warm-up finds faster")
+                         "(srz.parallel.LaneRenderer: consecutive steps overlap at their edges); 1 = one frameset on one "
+                         "stream; 0 = two lanes for steps of >= 64 frames, else one")
     ap.add_argument("--no-overlap", action="store_true", help="N>1 only: render and exchange back to back on one stream")
     ap.add_argument("--no-extras", action="store_true", help="N=1: skip the other BASELINE configs / scope draw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -394,8 +380,8 @@ def main():
                 traffic = None
         roof = rec["roofline"]
         roof.update({"traffic": traffic,
-                     "traffic_source": (f"{traffic_src}: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 --pmc passes of this command, per launch "
-                                        "(not measured in this run)") if traffic else None,
+                     "traffic_source": (f"{traffic_src}: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 --pmc passes of this command with --lanes 1 "
+                                        "(same bytes per step, kernels not overlapped), per step (not measured in this run)") if traffic else None,
                      "frac_of_measured_copy_6290": roof["achieved"] / HBM_MEASURED_COPY_GBS,
                      "kernel": "hot path = k_setup + k_bin + k_raster (+ k_raster_slow) + k_shade in line, k_clear beside k_raster/k_shade "
                                "on a second stream (one launch each per lane per step)",
@@ -430,7 +416,7 @@ def main():
         extras = []
         todo = [(w, f, s, "raster", args.lanes) for (w, f, s) in EXTRA_CASES if w != args.workload]
         todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster", args.lanes))
-        # the headline workload once more as two lanes on two streams (consecutive batches overlap at their edges)
+        # the headline workload once more the other way (one frameset on one stream / two lanes on two streams)
         todo.append((args.workload, args.frames, args.steps, args.scope, 2 if args.lanes == 1 else 1))
         for (w, f, s, scope, n_lanes) in todo:
             try:

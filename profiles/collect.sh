@@ -8,7 +8,11 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python3 bench.py --no-cpu-baseline --no-extras"
+# bench.py's default renders the batch as two lanes on two streams: their kernels overlap, so per-kernel durations and
+# per-launch counters are taken from the same command with --lanes 1 (one frameset, one stream: the bytes per step are the
+# same, the kernels do not overlap); the default command's own kernel statistics are kept beside them (trace_lanes)
+CMD="python3 bench.py --no-cpu-baseline --no-extras --lanes 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes -- python3 bench.py --no-cpu-baseline --no-extras > $OUT/bench_traced_lanes.json 2> $OUT/trace_lanes.log || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_traced.json 2> $OUT/trace.log || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log || exit 1

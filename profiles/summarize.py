@@ -38,6 +38,10 @@ def one(pattern):
 
 
 shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_stats.csv"))
+try:  # the default command (two lanes on two streams: the kernels of the lanes overlap; half a batch per launch)
+    shutil.copy(one("trace_lanes/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_lanes_kernel_stats.csv"))
+except AssertionError:
+    pass
 stats = {r["Name"]: r for r in csv.DictReader(open(one("trace/**/*kernel_stats.csv")))}
 per_kernel_us = {}
 for name, r in stats.items():
@@ -58,6 +62,7 @@ def pmc(dirname):
 
 fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
+traced = json.loads(open(os.path.join(src, "bench_traced.json")).read().strip().splitlines()[-1])  # the --lanes 1 run under the tracer
 out = {"tag": tag, "bench_line": bench, "avg_kernel_us": per_kernel_us, "pipeline_us_sum": sum(v for k, v in per_kernel_us.items() if k != "k_clear"),
        "note": "k_clear runs on a second stream beside k_raster/k_shade: its time overlaps theirs and is not in pipeline_us_sum",
        "pmc_avg_per_launch": {}, "units": "FETCH_SIZE/WRITE_SIZE in KiB (rocprofv3); bytes below = KiB*1024"}
@@ -79,7 +84,7 @@ t[bench["config"]["workload"]] = {"hbm_bytes_per_launch": tot_w + 2 * tot_f, "fr
                                   "frames_per_launch": bench["config"]["frames_per_step"]}
 json.dump(t, open(tfile, "w"), indent=1)
 print(json.dumps(out["hbm_bytes_per_launch"], indent=1))
-print(per_kernel_us, "events total ms:", bench["roofline"]["launch_ms"])
+print(per_kernel_us, "one-stream events total ms:", bench["roofline"]["one_stream"]["launch_ms"], "| traced --lanes 1 run:", traced["roofline"]["launch_ms"])
 
 # ---- the other BASELINE configs (tests/perf_probe.py under the same two profiler modes) ---------------------------------
 others = {}

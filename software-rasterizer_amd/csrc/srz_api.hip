@@ -345,8 +345,10 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (turns) {
     if (!ctx->ev_raster[0])
       for (int i = 0; i < srz_ctx::EV_RING; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_raster[i], hipEventDisableTiming));
-    if (ctx->raster_valid && ctx->raster_last_stream != s)
+    if (ctx->raster_valid && ctx->raster_last_stream != s) {
       HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_raster[(ctx->raster_next + srz_ctx::EV_RING - 1) % srz_ctx::EV_RING], 0));
+      a.other_streams = 1u;
+    }
   }
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
   launch_setup(a, fs->n_frames, fs->max_tris, stats, s);

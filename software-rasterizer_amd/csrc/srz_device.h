@@ -112,6 +112,7 @@ struct RenderArgs {
   uint32_t *tile_off;            // [frame][local band][tiles_x] first record in pool[], or UNLISTED
   uint32_t *slow_list;           // tiles (frame * tiles_per_frame + tile) left to the ordered rasteriser
   uint32_t *slow_count;
+  uint32_t other_streams;        // host hint: the previous render of this ctx went to another stream (lanes): k_shade's grid follows
   uint32_t clear_in_raster;      // small jobs: no k_clear is launched, k_raster's waves clear the tiles no bbox reaches
   uint32_t force_ordered;        // every touched tile goes to k_raster_slow (SRZ_ORDERED_RASTER, counting runs)
   uint32_t force_generic;        // every frame is shaded by the generic build of k_shade (counting runs)

@@ -2003,8 +2003,12 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s) {
   if (max_tiles == 0) return;
+  // One stream: a LARGE grid (a tile or two per workgroup: in-order hand-out, one-tile tail).  Renders interleaved on several
+  // streams (a.other_streams): a grid about as large as the machine's resident capacity, the workgroups striding through the
+  // lists — measured, 2 x 128 frames of 1024^2 on two streams: 16384 workgroups 1.10 ms per batch, 4096 1.08, 2560 1.07,
+  // 1280 1.065 (and on ONE stream 0.73 / 0.78 / — / 0.78 ms for k_shade alone)
   static const uint32_t env_grid = getenv("SRZ_SHADE_GRID") ? (uint32_t)atoi(getenv("SRZ_SHADE_GRID")) : 0u;
-  const uint32_t gcap = env_grid ? env_grid : 16384u;
+  const uint32_t gcap = env_grid ? env_grid : (a.other_streams ? 2048u : 16384u);
   dim3 grid((std::min(max_tiles, gcap) + 7u) & ~7u); // (a multiple of 8: workgroup b serves list b % 8)
   if (stats) { // (counting runs shade every frame with the generic build: force_generic)
     hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), 0, s, a);
