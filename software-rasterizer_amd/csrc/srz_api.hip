@@ -224,6 +224,8 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.force_ordered = 0, a.force_generic = 0, a.any_generic = fs->any_generic ? 1u : 0u;
   a.sdesc = fs->d_sdesc;
   a.vis = fs->d_vis;
+  static const bool no_vis16 = getenv("SRZ_NO_VIS16") != nullptr; // (A/B of the owner-id width)
+  a.vis16 = (!no_vis16 && fs->max_tris < 32768u) ? 1u : 0u;
   a.worklist = fs->d_worklist;
   a.work_count = fs->d_work_count;
   // (a list holds the tiles of every 8th frame; of fewer than 8 frames: any of them)

@@ -119,6 +119,7 @@ struct RenderArgs {
   uint32_t any_generic;          // some frame is not FD_FAST_SHADE (else the generic build only serves redo_list)
   uint32_t *redo_list;           // tiles (frame * tiles_per_frame + tile) the FAST build of k_shade hands to the generic one
   uint32_t *redo_count;
+  uint32_t vis16;                // the owner-id plane holds 16-bit ids (every frame of the set has < 32768 triangles)
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
   // k_shade's work: N_WORK_LISTS lists [FAST / generic build][frame % 8] of the tiles that have an owner, as
   // frame * tiles_per_frame + (lb*tiles_x + tx), in arrival order; work_cap entries each

@@ -806,6 +806,36 @@ __device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
 constexpr uint32_t S_CLASS_BIT = 0x80000000u;
 
+// The owner-id plane holds one id per pixel of the owned tiles: 32 bits (index | S_CLASS_BIT, NO_TRI = nobody), or — when
+// every frame of the set has fewer than 32768 triangles (RenderArgs::vis16) — 16 bits (index | 0x8000, 0xffff = nobody) at the
+// same pixel index: half the bytes k_raster writes and k_shade reads back (0.19 GB of a 256-frame step of config 2).
+__device__ __forceinline__ uint32_t id_pack16(uint32_t id) { return id == NO_TRI ? 0xffffu : ((id & 0x7fffu) | ((id >> 16) & 0x8000u)); }
+__device__ __forceinline__ uint32_t id_unpack16(uint32_t h) { return h == 0xffffu ? NO_TRI : ((h & 0x7fffu) | ((h & 0x8000u) << 16)); }
+__device__ __forceinline__ void vis_store4(uint32_t *vis, size_t e, const uint4 &id, bool v16) { // e % 4 == 0
+  if (v16) {
+    const u32x2 w = {id_pack16(id.x) | (id_pack16(id.y) << 16), id_pack16(id.z) | (id_pack16(id.w) << 16)};
+    *reinterpret_cast<u32x2 *>(reinterpret_cast<uint16_t *>(vis) + e) = w;
+  } else {
+    *reinterpret_cast<uint4 *>(vis + e) = id;
+  }
+}
+__device__ __forceinline__ void vis_store1(uint32_t *vis, size_t e, uint32_t id, bool v16) {
+  if (v16)
+    reinterpret_cast<uint16_t *>(vis)[e] = (uint16_t)id_pack16(id);
+  else
+    vis[e] = id;
+}
+__device__ __forceinline__ uint4 vis_load4(const uint32_t *vis, size_t e, bool v16) { // e % 4 == 0
+  if (v16) {
+    const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint16_t *>(vis) + e);
+    return make_uint4(id_unpack16(w.x & 0xffffu), id_unpack16(w.x >> 16), id_unpack16(w.y & 0xffffu), id_unpack16(w.y >> 16));
+  }
+  return *reinterpret_cast<const uint4 *>(vis + e);
+}
+__device__ __forceinline__ uint32_t vis_load1(const uint32_t *vis, size_t e, bool v16) {
+  return v16 ? id_unpack16(reinterpret_cast<const uint16_t *>(vis)[e]) : vis[e];
+}
+
 // Everything the shader needs about the owner triangle of one pixel, fetched in ONE round trip (7 independent loads)
 struct TriFetch {
   f32x4 q0, q1, q2, q3, q4, q5;
@@ -1276,13 +1306,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       float *gz = out0 + (size_t)ly * W + x4;
       const bool full = vec_ok && x4 + 3 <= tx1;
       if (tile_has_owner) {
-        uint32_t *gv = vis0 + (size_t)ly * W + x4;
+        const size_t ge = (size_t)(vis0 - a.vis) + (size_t)ly * W + x4;
         if (full) {
           store_nt(gz, z4[it]);                      // final: k_shade recomputes the depth it needs from the owner triangle
-          *reinterpret_cast<uint4 *>(gv) = id4[it]; // re-read by k_shade: keep it cacheable
+          vis_store4(a.vis, ge, id4[it], a.vis16 != 0u); // re-read by k_shade: keep it cacheable
         } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, gv[K_] = id4[it].M;
+  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, vis_store1(a.vis, ge + K_, id4[it].M, a.vis16 != 0u);
           SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
         }
@@ -1481,13 +1511,13 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         const bool full = vec_ok && x4 + 3 <= tx1;
         if (tile_has_owner) {
           const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
-          uint32_t *gv = vis0 + (size_t)ly * W + x4;
+          const size_t ge = (size_t)(vis0 - a.vis) + (size_t)ly * W + x4;
           if (full) {
             store_nt(gz, z4);
-            *reinterpret_cast<uint4 *>(gv) = id4;
+            vis_store4(a.vis, ge, id4, a.vis16 != 0u);
           } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4.M, gv[K_] = id4.M;
+  if (x4 + K_ <= tx1) gz[K_] = z4.M, vis_store1(a.vis, ge + K_, id4.M, a.vis16 != 0u);
             SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
           }
@@ -1619,11 +1649,11 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
     const bool in_tile = y <= ty1 && x4 <= tx1;
     const bool full = in_tile && ((W & 3) == 0) && x4 + 3 <= tx1;
     float *gz = out0 + (size_t)ly * W + x4;
-    const uint32_t *gv = vis0 + (size_t)ly * W + x4;
+    const size_t ge = (size_t)(vis0 - a.vis) + (size_t)ly * W + x4;
     float4 C0 = make_float4(0.f, 0.f, 0.f, 0.f), C1 = C0, C2 = C0;
     uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
     if (full) {
-      id4 = *reinterpret_cast<const uint4 *>(gv);
+      id4 = vis_load4(a.vis, ge, a.vis16 != 0u);
       if (!fused) { // keep the colour of pixels this call does not own
         C0 = *reinterpret_cast<const float4 *>(gz + plane);
         C1 = *reinterpret_cast<const float4 *>(gz + 2 * plane);
@@ -1632,7 +1662,7 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
     } else if (in_tile) {
 #define SRZ_LD(K_, M)                                                                                                  \
   if (x4 + K_ <= tx1) {                                                                                                \
-    id4.M = gv[K_];                                                                                                    \
+    id4.M = vis_load1(a.vis, ge + K_, a.vis16 != 0u);                                                                  \
     if (!fused) C0.M = gz[plane + K_], C1.M = gz[2 * plane + K_], C2.M = gz[3 * plane + K_];                           \
   }
       SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
