@@ -35,16 +35,16 @@ struct __attribute__((aligned(8))) BBox {
 };
 
 // One entry of a TILE's triangle list: everything the coverage/z pass needs, gathered once by k_bin so that the tile
-// waves read their work with ONE level of coalesced loads (one 64-byte line per entry).
-struct __attribute__((aligned(16))) RasterRec {
+// waves read their work with ONE level of coalesced loads (three 16-byte loads per entry).
+struct __attribute__((aligned(16))) RasterRec { // 48 bytes: three 16-byte loads
   float ax, ay, z0, bx, by, z1, cx, cy, z2;
   uint32_t bbx; // sx | sy << 16
   uint32_t bby; // ex | ey << 16
   uint32_t idx; // triangle index inside the frame (= submission order)
-  float v_inv;  // 1 / fmsub(ABx,ACy,ACx*ABy): "V" columns (src/Rasterizer.cpp:111-112)
-  float s_area; // ABx*ACy - ABy*ACx: scalar-tail columns (src/Rasterizer.cpp:61)
-  uint32_t _pad[2];
 };
+// (the per-triangle constants of the coverage tests — 1 / fmsub(ABx,ACy,ACx*ABy) for the V columns, ABx*ACy - ABy*ACx for the
+// S columns — are recomputed by k_raster from the positions, once per record and 64 records at a time: 16 bytes less to
+// write and read back per (triangle, tile) pair)
 
 // What the Shader object bound to a batch holds (type + texture), resolved on the host at render time
 struct __attribute__((aligned(8))) ShadeDescG {

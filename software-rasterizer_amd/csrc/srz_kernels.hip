@@ -6,7 +6,7 @@
 //
 //   k_vertex  one thread per face          (optional) the vertex stage, Scene::loadTriangleStream: meshes + matrices → srz_tri
 //   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox record
-//   k_bin     one WORKGROUP per 32-row band count / scan / fill of the BBox stream into UNORDERED per-tile lists of 64-byte
+//   k_bin     one WORKGROUP per 32-row band count / scan / fill of the BBox stream into UNORDERED per-tile lists of 48-byte
 //                                          RasterRec (positions + bbox + index + the per-triangle constants of both coverage
 //                                          tests), LDS atomics only; records come from a pool sized by what renders need
 //   k_clear   ~64 persistent workgroups    on a second stream beside k_raster / k_shade: the fused clear of every tile no
@@ -387,7 +387,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 //           records from the sub-pool of this workgroup (k_raster_slow serves the tiles of a band that does not fit)
 //   pass 2  the hits are queued per wave and flushed 64 at a time: one round trip of independent gathers (positions +
 //           bbox) per 64 hits, the per-triangle constants of both coverage tests are computed once here, and every
-//           (triangle, tile) pair becomes one 64-byte record at pool[band base + tile offset + slot]
+//           (triangle, tile) pair becomes one 48-byte record at pool[band base + tile offset + slot]
 // ================================================================================================================
 constexpr int BIN_MAX_WAVES = 8; // launched with 2, 4 or 8 waves: the walk is latency-bound, so short streams take small
                                  // workgroups (more of them resident per CU), long ones more waves per band
@@ -493,15 +493,12 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
       const SRZ_CAS float *p = &tris[t].pos[0][0];
       TriXY k;
       k.ax = p[0], k.ay = p[1], k.z0 = p[2], k.bx = p[3], k.by = p[4], k.z1 = p[5], k.cx = p[6], k.cy = p[7], k.z2 = p[8];
-      BranchMath bm;
-      tri_consts(bm, k);
       const f32x4 q0 = {k.ax, k.ay, k.z0, k.bx}, q1 = {k.by, k.z1, k.cx, k.cy};
       const f32x4 q2 = {k.z2, u2f_(r.x), u2f_(r.y), u2f_(t)};
-      const f32x4 q3 = {k.v_inv, k.s_area, 0.f, 0.f};
       const int tlo = (int)(int16_t)(r.x & 0xffff) >> 5, thi = (int)(int16_t)(r.y & 0xffff) >> 5;
       for (int tx = tlo; tx <= thi; ++tx) {
         f32x4 *o = reinterpret_cast<f32x4 *>(out + s_off[tx] + atomicAdd(&s_fill[tx], 1u));
-        o[0] = q0, o[1] = q1, o[2] = q2, o[3] = q3;
+        o[0] = q0, o[1] = q1, o[2] = q2;
       }
     }
   };
@@ -1108,19 +1105,28 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   //            never dropped
   uint32_t zfar = 0xffffffffu; // image of the tile's farthest depth when last read back (all ones: nothing can be dropped yet;
                                // depths only come down, so an old value stays a valid bound)
-  f32x4 n0, n1, n2, n3;
+  f32x4 n0, n1, n2;
   bool nv = (uint32_t)lane < cnt;
   {
     const uint32_t e = nv ? (uint32_t)lane : 0u;
-    n0 = recs[4 * e], n1 = recs[4 * e + 1], n2 = recs[4 * e + 2], n3 = recs[4 * e + 3];
+    n0 = recs[3 * e], n1 = recs[3 * e + 1], n2 = recs[3 * e + 2];
   }
   for (uint32_t base = 0; base < cnt; base += 64) {
-    const f32x4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+    const f32x4 r0 = n0, r1 = n1, r2 = n2;
+    // the per-triangle constants of the two coverage tests, once per record (a record carries 48 bytes, not these 8 more)
+    float rec_v_inv, rec_s_area;
+    {
+      TriXY k;
+      k.ax = r0.x, k.ay = r0.y, k.bx = r0.w, k.by = r1.x, k.cx = r1.z, k.cy = r1.w;
+      BranchMath bm;
+      tri_consts(bm, k);
+      rec_v_inv = k.v_inv, rec_s_area = k.s_area;
+    }
     const bool valid = nv;
     nv = base + 64 + lane < cnt;
     if (base + 64 < cnt) { // the next chunk is in flight while this one is rasterised
       const uint32_t e = nv ? base + 64 + lane : base;
-      n0 = recs[4 * e], n1 = recs[4 * e + 1], n2 = recs[4 * e + 2], n3 = recs[4 * e + 3];
+      n0 = recs[3 * e], n1 = recs[3 * e + 1], n2 = recs[3 * e + 2];
     }
     const uint32_t my_idx = f2u(r2.w);
     const Geo G = geometry(r0, r1, r2, valid);
@@ -1141,7 +1147,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       const float dx = __builtin_fmaxf(__builtin_fmaxf(r0.x, r0.w), r1.z) - __builtin_fminf(__builtin_fminf(r0.x, r0.w), r1.z);
       const float dy = __builtin_fmaxf(__builtin_fmaxf(r0.y, r1.x), r1.w) - __builtin_fminf(__builtin_fminf(r0.y, r1.x), r1.w);
       const float zs = (G.zmin - (zmax - G.zmin) * 0.00390625f) * 0.99999905f;
-      if (dx * dx + dy * dy <= 1024.0f * __builtin_fabsf(r3.y) && zmax < 1e30f && zs > 0.0f) znear_s = zkey_of(zs);
+      if (dx * dx + dy * dy <= 1024.0f * __builtin_fabsf(rec_s_area) && zmax < 1e30f && zs > 0.0f) znear_s = zkey_of(zs);
     }
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
     const bool mine = G.ok && group == gi;
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       const int src = (int)((m - 1u) & 63u) * 4;
       const float ax = bperm_f(src, r0.x), ay = bperm_f(src, r0.y), z0 = bperm_f(src, r0.z), bx = bperm_f(src, r0.w);
       const float by = bperm_f(src, r1.x), z1 = bperm_f(src, r1.y), cx = bperm_f(src, r1.z), cy = bperm_f(src, r1.w);
-      const float z2 = bperm_f(src, r2.x), v_inv = bperm_f(src, r3.x);
+      const float z2 = bperm_f(src, r2.x), v_inv = bperm_f(src, rec_v_inv);
       const uint32_t g = bperm_u(src, geom), idx = bperm_u(src, my_idx), o = bperm_u(src, offs);
       const uint32_t item = P0 + (uint32_t)lane, i = item - (o & 0xffffu), ns = (g >> 16) & 7u;
       // row = i / ns: (i + 0.5) / ns is at least 1 / 8 away from every integer, far more than the error of v_rcp
@@ -1220,7 +1226,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       const int src = (int)((m - 1u) & 63u) * 4;
       const float ax = bperm_f(src, r0.x), ay = bperm_f(src, r0.y), z0 = bperm_f(src, r0.z), bx = bperm_f(src, r0.w);
       const float by = bperm_f(src, r1.x), z1 = bperm_f(src, r1.y), cx = bperm_f(src, r1.z), cy = bperm_f(src, r1.w);
-      const float z2 = bperm_f(src, r2.x), s_area = bperm_f(src, r3.y);
+      const float z2 = bperm_f(src, r2.x), s_area = bperm_f(src, rec_s_area);
       const uint32_t g = bperm_u(src, geom), idx = bperm_u(src, my_idx), o = bperm_u(src, offs);
       const uint32_t item = P0 + (uint32_t)lane, i = item - (o >> 16), w = (g >> 19) & 7u;
       const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w)), col = i - __umul24(row, w);
