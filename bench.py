@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 HBM_MEASURED_COPY_GBS = 6290.0
 XGMI_LINK_GBS = 153.0  # per link, per direction (7 links per GPU)
 # the other GPU configs of BASELINE.json, whole frames on one GPU: (workload, frames per step, steps)
-EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 64, 20), ("spot_x8_overdraw_4096", 64, 20),
+EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 128, 20), ("spot_x8_overdraw_4096", 64, 20),
                ("readme_spot_crate_1024", 256, 20)]  # (+ the scene of the reference's one published raster figure)
 
 
