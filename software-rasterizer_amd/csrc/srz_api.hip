@@ -97,6 +97,7 @@ struct srz_frameset {
   RasterRec *d_pool = nullptr;
   uint32_t pool_sub_cap = 0, pool_n_sub = 1;
   uint32_t *d_pool_heads = nullptr, *h_pool_heads = nullptr;
+  static constexpr int DEMAND_PARTS = 8; // h_pool_heads holds one copy of the allocators' lines per sub-batch of a large render
   uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_slow_list = nullptr, *d_slow_count = nullptr;
   uint32_t *d_redo_list = nullptr; // (its counter is d_slow_count[1])
   bool any_fast = false, any_generic = true; // which builds of k_shade the frames need (classify_frames)
@@ -312,8 +313,8 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   { // (h_pool_heads is pinned host memory the rasteriser's first workgroup stores into: whatever it holds is a demand some
     // finished or running render of this set really had — a stale value only delays the growth by a render)
     uint32_t need = 0;
-    for (uint32_t i = 0; i < fs->pool_n_sub; ++i) {
-      const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[i * CNT_STRIDE];
+    for (uint32_t i = 0; i < fs->pool_n_sub * (uint32_t)srz_frameset::DEMAND_PARTS; ++i) { // (every sub-batch's region)
+      const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[((i / fs->pool_n_sub) * 64u + i % fs->pool_n_sub) * CNT_STRIDE];
       if (v > need) need = v;
     }
     if (need > fs->pool_sub_cap) {
@@ -353,54 +354,82 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     }
   }
   if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
-  launch_setup(a, fs->n_frames, fs->max_tris, stats, s);
-  launch_bin(a, fs->n_frames, fs->max_tris, s);
-  if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
-  // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in line (small jobs)
+  // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in the rasteriser (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
   const bool side = any_fused && fs->max_tiles >= 8192;
-  unsigned ev = 0;
-  // the record pool's demand of this render → host (word 0 of every allocator's line).  No event: the next render reads
-  // whatever has arrived (see the growth check above).  The latency build of k_raster stores it itself.
-  auto copy_demand = [&](hipStream_t cs) {
-    HIP_TRY(ctx, hipMemcpyAsync(fs->h_pool_heads, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, cs));
-    return (int)SRZ_OK;
-  };
-  if (side) {
-    if (!ctx->stream2) {
-      // The clear must run BESIDE the launch stream, so it may not share a hardware queue with it: HIP deals its streams
-      // round-robin onto a few hardware queues (seen: the caller's stream and this one on the same queue — the clear then ran
-      // in front of k_raster instead of beside it, +20 % per render).  Streams of another priority live on queues of their own;
-      // the clear is throttled by its grid size, not by priority, so the highest one costs the rasteriser nothing.
-      int prio_least = 0, prio_greatest = 0;
-      HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-      HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_greatest));
-      for (int i = 0; i < srz_ctx::EV_RING; ++i) {
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
-      }
+  if (side && !ctx->stream2) {
+    // The clear must run BESIDE the launch stream, so it may not share a hardware queue with it: HIP deals its streams
+    // round-robin onto a few hardware queues (seen: the caller's stream and this one on the same queue — the clear then ran
+    // in front of k_raster instead of beside it, +20 % per render).  Streams of another priority live on queues of their own;
+    // the clear is throttled by its grid size, not by priority, so the highest one costs the rasteriser nothing.
+    int prio_least = 0, prio_greatest = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_greatest));
+    for (int i = 0; i < srz_ctx::EV_RING; ++i) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
     }
-    ev = ctx->ev_next++ % srz_ctx::EV_RING;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[ev], s));
-    hipStream_t side_s = ctx->stream2;
-    HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
-    launch_clear(a, fs->max_tiles, true, side_s);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
-    if (int rc = copy_demand(side_s)) return rc; // (behind the join: off the critical path)
-  } else if (any_fused) {
-    a.clear_in_raster = 1u; // (small job: the rasteriser's own waves clear the tiles no bbox reaches — one kernel less in line)
   }
-  launch_raster(a, fs->n_frames, stats, s);
-  if (turns) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_raster[ctx->raster_next++ % srz_ctx::EV_RING], s));
-    ctx->raster_last_stream = s, ctx->raster_valid = true;
+  if (!side && any_fused) a.clear_in_raster = 1u; // (small job: the rasteriser's own waves clear the tiles no bbox reaches)
+  // A LARGE set is rendered as sub-batches of whole frames one after the other on the same stream: what k_raster leaves for
+  // k_shade (depth, owner ids) and k_bin for k_raster (records) stays in the 256 MiB Infinity Cache only while the frames in
+  // flight are few — config 2 at 128 / 256 / 384 / 512 frames per launch set: 0.539 / 0.545 / 0.499 / 0.490 of the roofline.
+  // A sub-batch is a view: every per-frame array from its first frame on; counters, record pool and work lists are shared
+  // (k_setup resets them, and stream order keeps one sub-batch's kernels behind the previous one's).  Counting runs and the
+  // per-kernel timing mode render in one piece.
+  const int n_all = fs->n_frames;
+  int chunk = n_all;
+  static const int sub_env = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0; // (tuning: frames per sub-batch)
+  const int sub = sub_env > 0 ? sub_env : 192;
+  if (n_all >= sub + sub / 2 + 32 && !stats && !detailed) {
+    const int parts = (n_all + sub - 1) / sub;
+    chunk = ((n_all + parts - 1) / parts + 7) / 8 * 8;
   }
-  if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
-  launch_shade(a, fs->max_tiles, stats, fs->any_fast, fs->any_generic, s);
-  if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
-  else if (!raster_four_waves(a))
-    if (int rc = copy_demand(s)) return rc;
+  const size_t tpf = (size_t)fs->n_local_bands * fs->tiles_x;
+  int part = 0;
+  for (int f0 = 0; f0 < n_all; f0 += chunk, ++part) {
+    RenderArgs v = a;
+    const int n = std::min(chunk, n_all - f0);
+    if (n != n_all) {
+      v.frames += f0, v.n_frames = (uint32_t)n;
+      v.vis += (size_t)f0 * fs->local_rows * (size_t)fs->width;
+      v.tile_cnt += (size_t)f0 * tpf, v.tile_off += (size_t)f0 * tpf;
+      v.out += (size_t)f0 * a.frame_stride;
+      v.work_cap = (uint32_t)((size_t)(n < 8 ? n : (n + 7) / 8) * tpf);
+    }
+    const uint32_t tiles = (uint32_t)((size_t)n * tpf);
+    launch_setup(v, n, fs->max_tris, stats, s);
+    launch_bin(v, n, fs->max_tris, s);
+    if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
+    // the record pool's demand of this (sub-)render → host (word 0 of every allocator's line; one region per sub-batch).  No
+    // event: the next render reads whatever has arrived (see the growth check above).  The latency build of k_raster stores it itself.
+    auto copy_demand = [&](hipStream_t cs) {
+      uint32_t *dst = fs->h_pool_heads + (size_t)std::min(part, srz_frameset::DEMAND_PARTS - 1) * CNT_STRIDE * 64;
+      HIP_TRY(ctx, hipMemcpyAsync(dst, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, cs));
+      return (int)SRZ_OK;
+    };
+    unsigned ev = 0;
+    if (side) {
+      ev = ctx->ev_next++ % srz_ctx::EV_RING;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[ev], s));
+      hipStream_t side_s = ctx->stream2;
+      HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
+      launch_clear(v, tiles, true, side_s);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
+      if (int rc = copy_demand(side_s)) return rc; // (behind the join: off the critical path)
+    }
+    launch_raster(v, n, stats, s);
+    if (turns) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_raster[ctx->raster_next++ % srz_ctx::EV_RING], s));
+      ctx->raster_last_stream = s, ctx->raster_valid = true;
+    }
+    if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
+    launch_shade(v, tiles, stats, fs->any_fast, fs->any_generic, s);
+    if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
+    else if (!raster_four_waves(v))
+      if (int rc = copy_demand(s)) return rc;
+  }
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -641,8 +670,8 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64)); // (one cache line per allocator)
     // what a render asked of each sub-pool comes back through pinned, device-mapped host memory: small jobs store it from
     // k_raster's first workgroup (no copy, no event, no query on the launch path), batches copy it on the clear's side stream
-    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64, hipHostMallocMapped | hipHostMallocCoherent));
-    if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * 64);
+    FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64 * srz_frameset::DEMAND_PARTS, hipHostMallocMapped | hipHostMallocCoherent));
+    if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * 64 * srz_frameset::DEMAND_PARTS);
     FS_TRY(dev_alloc((void **)&fs->d_tile_cnt, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_tile_off, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));

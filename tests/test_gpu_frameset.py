@@ -363,3 +363,28 @@ def test_two_lanes_at_batch_size_take_turns_and_match_the_oracle(orc):
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     lr.close()
     ctx.close()
+
+
+def test_large_set_rendered_as_sub_batches_matches_the_oracle(orc):
+    """a set of >= 320 frames is rendered as sub-batches of whole frames one after the other (shared counters, pool and work
+    lists): 328 small frames, twice in a row, every frame the oracle's; the demand of every sub-batch reaches the pool"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    uniq = [scenes.config2(i, size=96, shader=(abi.SHADER_TEXTURE, abi.SHADER_PHONG)[i % 2]) for i in range(36)]
+    frames = [uniq[(7 * i) % 36] for i in range(328)]
+    fs = ctx.frameset(frames)
+    out = torch.full(fs.out_shape, float("nan"), dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ref = {}
+    for i in range(328):
+        k = (7 * i) % 36
+        if k not in ref:
+            ref[k] = orc.draw(uniq[k])[1]
+        for p in range(4):
+            assert np.array_equal(bits(got[i, p]), bits(ref[k][p])), (i, p)
+    fs.close()
+    ctx.close()
