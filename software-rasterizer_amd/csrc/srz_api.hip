@@ -353,7 +353,10 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       a.other_streams = 1u;
     }
   }
-  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, s); // vertex stage on the device
+  // vertex stage on the device; outside counting runs it does the triangles' setup too (cull + bounding box from the registers
+  // that hold the transformed triangle), and k_chunks replaces k_setup below
+  const bool vertex_setup = fs->d_draws != nullptr && !stats;
+  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, fs->d_frames, vertex_setup ? fs->d_bbox : nullptr, s);
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in the rasteriser (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
@@ -399,7 +402,10 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       v.work_cap = (uint32_t)((size_t)(n < 8 ? n : (n + 7) / 8) * tpf);
     }
     const uint32_t tiles = (uint32_t)((size_t)n * tpf);
-    launch_setup(v, n, fs->max_tris, stats, s);
+    if (vertex_setup)
+      launch_chunks(v, n, fs->max_tris, s);
+    else
+      launch_setup(v, n, fs->max_tris, stats, s);
     launch_bin(v, n, fs->max_tris, s);
     if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
     // the record pool's demand of this (sub-)render → host (word 0 of every allocator's line; one region per sub-batch).  No
@@ -765,7 +771,7 @@ int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frame
       const srz_mesh_draw &dr = frames[f].draws[d];
       const srz_ctx::MeshSlot &m = ctx->mesh[dr.mesh_id];
       DrawDesc dd{};
-      dd.verts = m.d_verts, dd.faces = m.d_faces, dd.n_faces = m.n_faces, dd.tri_off = first;
+      dd.verts = m.d_verts, dd.faces = m.d_faces, dd.n_faces = m.n_faces, dd.tri_off = first, dd.frame = (uint32_t)f;
       dd.zscale = frames[f].zscale, dd.zoffset = frames[f].zoffset;
       std::memcpy(dd.ndc_mvp, dr.ndc_mvp, sizeof dd.ndc_mvp), std::memcpy(dd.normal_m, dr.normal_m, sizeof dd.normal_m);
       h.push_back(dd);

@@ -58,6 +58,7 @@ struct DrawDesc {
   const uint32_t *faces;
   uint32_t n_faces;
   uint32_t tri_off; // first output triangle (global index into tris[])
+  uint32_t frame;   // the frame this draw belongs to (k_vertex's own triangle setup reads its size and eye)
   float zscale, zoffset;
   float ndc_mvp[16], normal_m[16];
 };
@@ -136,7 +137,9 @@ struct RenderArgs {
   unsigned long long *timeline; // diagnostic (STATS variant only): per tile {start, end (wall clock 100 MHz), hw_id, blocks}
 };
 
-void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, hipStream_t s);
+void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out,
+                   hipStream_t s);
+void launch_chunks(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
 void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);

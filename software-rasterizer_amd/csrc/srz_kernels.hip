@@ -268,7 +268,45 @@ __device__ __forceinline__ void xform_div_w(const SRZ_CAS float *m, float x, flo
   ox = r[0] / r[3], oy = r[1] / r[3], oz = r[2] / r[3];
 }
 
-__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris) {
+// Per triangle: finite check, backface test, bounding box (src/Triangle.cpp:147-151,243-257; Rasterizer.cpp:203) — shared by
+// k_setup (uploaded streams) and k_vertex (scenesets: the triangle is still in registers).  Returns "kept"; a culled or
+// non-finite triangle gets the empty box.
+__device__ __forceinline__ bool setup_triangle(const float (&P)[9], int W, int H, float ex, float ey, float ez, bool live, BBox &bb) {
+  const float A0 = P[0], A1 = P[1], A2 = P[2], B0 = P[3], B1 = P[4], B2 = P[5], C0 = P[6], C1 = P[7], C2 = P[8];
+  bb.sx = 1, bb.sy = 1, bb.ex = 0, bb.ey = 0;
+  const bool finite = live && __builtin_isfinite(A0) && __builtin_isfinite(A1) && __builtin_isfinite(A2) && __builtin_isfinite(B0) &&
+                      __builtin_isfinite(B1) && __builtin_isfinite(B2) && __builtin_isfinite(C0) && __builtin_isfinite(C1) &&
+                      __builtin_isfinite(C2);
+  bool keep = false;
+  if (finite) {
+    float e1x = B0 - A0, e1y = B1 - A1, e1z = B2 - A2, e2x = C0 - A0, e2y = C1 - A1, e2z = C2 - A2;
+    float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
+    BranchMath bm;
+    normalize3(bm, nx, ny, nz);
+    keep = !(dot3(nx, ny, nz, ex, ey, ez) > 0.0f);
+  }
+  if (keep) {
+    float mnx = A0, mxx = A0, mny = A1, mxy = A1;
+    if (B0 < mnx) mnx = B0;
+    if (C0 < mnx) mnx = C0;
+    if (mxx < B0) mxx = B0;
+    if (mxx < C0) mxx = C0;
+    if (B1 < mny) mny = B1;
+    if (C1 < mny) mny = C1;
+    if (mxy < B1) mxy = B1;
+    if (mxy < C1) mxy = C1;
+    // clamp(trunc(v),0,W-1) == trunc(clamp(v,0,W-1)) for every finite v
+    bb.sx = (int16_t)(int)std_clamp(mnx, 0.0f, (float)(W - 1));
+    bb.ex = (int16_t)(int)std_clamp(mxx, 0.0f, (float)(W - 1));
+    bb.sy = (int16_t)(int)std_clamp(mny, 0.0f, (float)(H - 1));
+    bb.ey = (int16_t)(int)std_clamp(mxy, 0.0f, (float)(H - 1));
+  }
+  return keep;
+}
+
+// (bbox_out != null: the triangle's setup — cull + bounding box — is done here too, from the registers that hold it; k_chunks
+// then only reduces the boxes to the chunks' row ranges and the 96-byte triangles are not read back by a k_setup)
+__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out) {
   const SRZ_CAS DrawDesc *d = as_const(draws) + blockIdx.y;
   const uint32_t n_faces = d->n_faces;
   const SRZ_CAS srz_vertex *verts = as_const(d->verts);
@@ -288,6 +326,13 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
       t.uv[k][0] = v->uv[0], t.uv[k][1] = v->uv[1];
     }
     tris[d->tri_off + f] = t;
+    if (bbox_out) {
+      const SRZ_CAS FrameDesc *fd = as_const(frames) + d->frame;
+      const float P[9] = {t.pos[0][0], t.pos[0][1], t.pos[0][2], t.pos[1][0], t.pos[1][1], t.pos[1][2], t.pos[2][0], t.pos[2][1], t.pos[2][2]};
+      BBox bb;
+      (void)setup_triangle(P, fd->width, fd->height, fd->eye[0], fd->eye[1], fd->eye[2], true, bb);
+      bbox_out[d->tri_off + f] = bb;
+    }
   }
 }
 
@@ -309,38 +354,14 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
   for (uint32_t t = blockIdx.x * 256 + threadIdx.x; (t & ~63u) < n_tris; t += gridDim.x * 256) { // whole waves
     const bool live = t < n_tris;
     const SRZ_CAS float *p = as_const(&a.tris[tri_off + (live ? t : 0u)].pos[0][0]);
-    float A0 = p[0], A1 = p[1], A2 = p[2], B0 = p[3], B1 = p[4], B2 = p[5], C0 = p[6], C1 = p[7], C2 = p[8];
+    const float P[9] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
     BBox bb;
-    bb.sx = 1, bb.sy = 1, bb.ex = 0, bb.ey = 0;
-    bool finite = live && __builtin_isfinite(A0) && __builtin_isfinite(A1) && __builtin_isfinite(A2) && __builtin_isfinite(B0) &&
-                  __builtin_isfinite(B1) && __builtin_isfinite(B2) && __builtin_isfinite(C0) && __builtin_isfinite(C1) &&
-                  __builtin_isfinite(C2);
-    bool keep = false;
-    if (finite) {
-      float e1x = B0 - A0, e1y = B1 - A1, e1z = B2 - A2, e2x = C0 - A0, e2y = C1 - A1, e2z = C2 - A2;
-      float nx = e1y * e2z - e2y * e1z, ny = e1z * e2x - e2z * e1x, nz = e1x * e2y - e2x * e1y;
-      BranchMath bm;
-      normalize3(bm, nx, ny, nz);
-      keep = !(dot3(nx, ny, nz, ex, ey, ez) > 0.0f);
-    }
-    if (keep) {
-      float mnx = A0, mxx = A0, mny = A1, mxy = A1;
-      if (B0 < mnx) mnx = B0;
-      if (C0 < mnx) mnx = C0;
-      if (mxx < B0) mxx = B0;
-      if (mxx < C0) mxx = C0;
-      if (B1 < mny) mny = B1;
-      if (C1 < mny) mny = C1;
-      if (mxy < B1) mxy = B1;
-      if (mxy < C1) mxy = C1;
-      // clamp(trunc(v),0,W-1) == trunc(clamp(v,0,W-1)) for every finite v
-      bb.sx = (int16_t)(int)std_clamp(mnx, 0.0f, (float)(W - 1));
-      bb.ex = (int16_t)(int)std_clamp(mxx, 0.0f, (float)(W - 1));
-      bb.sy = (int16_t)(int)std_clamp(mny, 0.0f, (float)(H - 1));
-      bb.ey = (int16_t)(int)std_clamp(mxy, 0.0f, (float)(H - 1));
-      if (STATS) tests += (unsigned long long)(bb.ex - bb.sx + 1) * (unsigned long long)(bb.ey - bb.sy + 1);
-    } else if (STATS && live) {
-      n_culled++;
+    const bool keep = setup_triangle(P, W, H, ex, ey, ez, live, bb);
+    if (STATS) {
+      if (keep)
+        tests += (unsigned long long)(bb.ex - bb.sx + 1) * (unsigned long long)(bb.ey - bb.sy + 1);
+      else if (live)
+        n_culled++;
     }
     if (live) bbox_out[tri_off + t] = bb;
     // rows spanned by the kept triangles of this 64-triangle chunk (= this wave's 64 consecutive t): lets k_bin skip
@@ -353,6 +374,29 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
     if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
     if (tests) atomicAdd(&a.stats[ST_PIXEL_TESTS], tests);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[ST_TRIS], (unsigned long long)n_tris);
+  }
+}
+
+// k_chunks — scenesets: k_vertex has written the bounding boxes; what is left of k_setup is the reset of the per-render
+// counters and the row range of every 64-triangle chunk (8 bytes read per triangle instead of 96)
+__global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x < N_WORK_LISTS) a.work_count[threadIdx.x * CNT_STRIDE] = 0u, a.work_count[threadIdx.x * CNT_STRIDE + 1] = 0u;
+    if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x * CNT_STRIDE] = 0u;
+    if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
+  }
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
+  const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
+  const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + tri_off));
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; (t & ~63u) < n_tris; t += gridDim.x * 256) { // whole waves
+    int lo = 0x7fff, hi = -1;
+    if (t < n_tris) {
+      const u32x2 r = bbox[t];
+      const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
+      if (sx <= ex) lo = sy, hi = ey; // (the empty box of a culled triangle: sx > ex)
+    }
+    for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));
+    if ((threadIdx.x & 63) == 0) a.chunk_rows[fd->chunk_off + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
   }
 }
 
@@ -1997,11 +2041,19 @@ __global__ void k_tex_convert(const uint8_t *bgr, int w, int h, int row_stride, 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, hipStream_t s) {
+void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out,
+                   hipStream_t s) {
   if (n_draws == 0 || max_faces == 0) return;
   dim3 grid((max_faces + 255) / 256, n_draws);
   if (grid.x > 1024) grid.x = 1024;
-  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris);
+  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris, frames, bbox_out);
+}
+
+void launch_chunks(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s) {
+  if (n_frames <= 0 || max_tris == 0) return;
+  dim3 grid((max_tris + 255) / 256, n_frames);
+  if (grid.x > 4096) grid.x = 4096;
+  hipLaunchKernelGGL(k_chunks, grid, dim3(256), 0, s, a);
 }
 
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s) {
