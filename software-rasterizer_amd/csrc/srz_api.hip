@@ -383,9 +383,13 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // per-kernel timing mode render in one piece.
   const int n_all = fs->n_frames;
   int chunk = n_all;
-  static const int sub_env = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0; // (tuning: frames per sub-batch)
-  const int sub = sub_env > 0 ? sub_env : 192;
-  if (n_all >= sub + sub / 2 + 32 && !stats && !detailed) {
+  // The sub-batch size is 192 frames' worth of 1024^2 (≈ 197 k tiles: the measured sweet spot), in frames of THIS set — a
+  // rank of an 8-GPU job holds an eighth of every frame and takes 1536 of them at a time; frames so large that fewer than 64
+  // make a sub-batch are left alone (nothing of theirs fits the cache either way).
+  const int sub_env = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0; // (tuning / tests: frames per sub-batch; read per render)
+  const size_t tiles_per_frame = std::max<size_t>((size_t)fs->n_local_bands * fs->tiles_x, 1);
+  const int sub = sub_env > 0 ? sub_env : (int)std::min<size_t>((192u * 1024u / tiles_per_frame + 7u) / 8u * 8u, 1u << 20);
+  if (sub >= 64 && n_all >= sub + sub / 2 + 32 && !stats && !detailed) {
     const int parts = (n_all + sub - 1) / sub;
     chunk = ((n_all + parts - 1) / parts + 7) / 8 * 8;
   }

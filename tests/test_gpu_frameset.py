@@ -365,10 +365,12 @@ def test_two_lanes_at_batch_size_take_turns_and_match_the_oracle(orc):
     ctx.close()
 
 
-def test_large_set_rendered_as_sub_batches_matches_the_oracle(orc):
-    """a set of >= 320 frames is rendered as sub-batches of whole frames one after the other (shared counters, pool and work
-    lists): 328 small frames, twice in a row, every frame the oracle's; the demand of every sub-batch reaches the pool"""
+def test_large_set_rendered_as_sub_batches_matches_the_oracle(orc, monkeypatch):
+    """a large set is rendered as sub-batches of whole frames one after the other (shared counters, pool and work lists; the
+    size is 192 frames' worth of 1024^2 in tiles — forced to 104 frames here, small frames being cheap to check): 328 frames,
+    twice in a row, every frame the oracle's"""
     import srz
+    monkeypatch.setenv("SRZ_SUB_BATCH", "104")
     ctx = srz.Context(0)
     ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
     uniq = [scenes.config2(i, size=96, shader=(abi.SHADER_TEXTURE, abi.SHADER_PHONG)[i % 2]) for i in range(36)]
