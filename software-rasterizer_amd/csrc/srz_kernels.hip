@@ -198,7 +198,11 @@ __device__ __forceinline__ float pow_cr(float x, float p) {
 
 // x^150 (the reference's Shader::p, src/Shader.cpp:10) as a fixed chain: the very multiplications pow_cr's loop performs
 // for n = 150 = 0b10010110, in the same order (r = x^2 · x^4 · x^16 · x^128), without the loop
+// x <= 0.5 gives x^150 <= 2^-150, which rounds to +0 in binary32 (2^-150 itself is the tie below the smallest denormal: to
+// even = 0): when no lane of the wave is above 0.5 — the half-vector more than 60 degrees off the normal everywhere in the
+// chunk, the common case away from a highlight — the chain is skipped.  (A NaN is not "<= 0.5": it takes the chain.)
 __device__ __forceinline__ float pow150_cr(float x) {
+  if (__ballot(!(x <= 0.5f)) == 0ull) return 0.0f;
   const double b1 = (double)x, b2 = b1 * b1, b4 = b2 * b2, b8 = b4 * b4, b16 = b8 * b8, b32 = b16 * b16, b64 = b32 * b32,
                b128 = b64 * b64;
   double r = b2 * b4;
