@@ -233,7 +233,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=15,
                     help="untimed steps first; the first ~13 steps after idle run up to 10 %% slower (clock ramp, first-touch "
-                         "of the record pool): tests/step_series_probe.py prints the series")
+                         "of the record pool): tools/step_series_probe.py prints the series")
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", default="spot_texture_1024")
     ap.add_argument("--scope", choices=["raster", "draw"], default="raster",

@@ -21,7 +21,7 @@ python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.log || exit 1
 # the other BASELINE configs: kernel-trace stats + SQ counters of the dev probe (whole frames on one GPU)
 for c in "3 64" "4 32" "5 16"; do
   n=${c%% *}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c$n -- python3 tests/perf_probe.py $c 10 > $OUT/probe_c$n.log 2>&1 || exit 1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq_c$n -- python3 tests/perf_probe.py $c 4 > $OUT/probe_pmc_c$n.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c$n -- python3 tools/perf_probe.py $c 10 > $OUT/probe_c$n.log 2>&1 || exit 1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq_c$n -- python3 tools/perf_probe.py $c 4 > $OUT/probe_pmc_c$n.log 2>&1 || exit 1
 done
 ls -R $OUT | head -40

@@ -94,14 +94,20 @@ struct srz_frameset {
   // per-tile triangle lists: records in a pool of n_sub sub-pools (srz_device.h, RenderArgs); every render reports what
   // it asked of each sub-pool (h_pool_heads: mapped host memory the device stores into), and a render that finds the previous demand
   // above the capacity grows the pool first — so the memory is O(triangle-tile pairs), not O(bands x triangles)
-  RasterRec *d_pool = nullptr;
+  uint32_t *d_pool = nullptr; // tile lists: triangle indices
+  PrepTri *d_prep = nullptr;
   uint32_t pool_sub_cap = 0, pool_n_sub = 1;
+  bool pool_sized = false; // the first render has sized the pool by its own demand (render_impl)
   uint32_t *d_pool_heads = nullptr, *h_pool_heads = nullptr;
   static constexpr int DEMAND_PARTS = 8; // h_pool_heads holds one copy of the allocators' lines per sub-batch of a large render
-  uint32_t *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_slow_list = nullptr, *d_slow_count = nullptr;
+  uint2 *d_tile_info = nullptr;
+  uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr;
   uint32_t *d_redo_list = nullptr; // (its counter is d_slow_count[1])
   bool any_fast = false, any_generic = true; // which builds of k_shade the frames need (classify_frames)
   uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr;
+  uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
+  uint2 *d_band_ent = nullptr;     // and entries [group][ENT_PER_GROUP]
+  uint64_t total_groups = 0;
   ShadeDescG *d_sdesc = nullptr;
   DrawDesc *d_draws = nullptr; // device vertex stage (srz_sceneset_create), else null
   // scenesets keep everything srz_sceneset_update rewrites in ONE device block [FrameDesc | lights | DrawDesc] that is
@@ -186,10 +192,10 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_batches);
   (void)hipFree(fs->d_lights);
   (void)hipFree(fs->d_pool);
+  (void)hipFree(fs->d_prep);
   (void)hipFree(fs->d_pool_heads);
   if (fs->h_pool_heads) (void)hipHostFree(fs->h_pool_heads);
-  (void)hipFree(fs->d_tile_cnt);
-  (void)hipFree(fs->d_tile_off);
+  (void)hipFree(fs->d_tile_info);
   (void)hipFree(fs->d_slow_list);
   (void)hipFree(fs->d_slow_count);
   (void)hipFree(fs->d_redo_list);
@@ -197,6 +203,8 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_worklist);
   (void)hipFree(fs->d_work_count);
   (void)hipFree(fs->d_chunk_rows);
+  (void)hipFree(fs->d_band_desc);
+  (void)hipFree(fs->d_band_ent);
   (void)hipFree(fs->d_sdesc);
   (void)hipFree(fs->d_draws);
 }
@@ -207,17 +215,19 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.tris = fs->d_tris;
   a.bbox = fs->d_bbox;
   a.chunk_rows = fs->d_chunk_rows;
+  a.band_desc = fs->d_band_desc;
+  a.band_ent = fs->d_band_ent;
   a.tri_batch = fs->d_tri_batch;
   a.batches = fs->d_batches;
   a.lights = fs->d_lights;
   a.tex = ctx->d_tex;
   a.pool = fs->d_pool;
+  a.prep = fs->d_prep;
   a.pool_heads = fs->d_pool_heads;
   a.pool_demand = fs->h_pool_heads; // (hipHostMallocMapped: the same address on the device)
   a.pool_sub_cap = fs->pool_sub_cap;
   a.pool_sub_mask = fs->pool_n_sub - 1u;
-  a.tile_cnt = fs->d_tile_cnt;
-  a.tile_off = fs->d_tile_off;
+  a.tile_info = fs->d_tile_info;
   a.slow_list = fs->d_slow_list;
   a.slow_count = fs->d_slow_count;
   a.redo_list = fs->d_redo_list;
@@ -321,8 +331,8 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       HIP_TRY(ctx, hipDeviceSynchronize());
       const uint64_t cap = (uint64_t)need + need / 4u + 64u;
       if (cap * fs->pool_n_sub >= 0xffffffffull) return fail(ctx, SRZ_E_NOMEM, "tile lists exceed 2^32 records; split the batch");
-      RasterRec *p = nullptr;
-      HIP_TRY(ctx, hipMalloc(&p, sizeof(RasterRec) * cap * fs->pool_n_sub));
+      uint32_t *p = nullptr;
+      HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * cap * fs->pool_n_sub));
       (void)hipFree(fs->d_pool);
       fs->d_pool = p, fs->pool_sub_cap = (uint32_t)cap;
     }
@@ -356,7 +366,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // vertex stage on the device; outside counting runs it does the triangles' setup too (cull + bounding box from the registers
   // that hold the transformed triangle), and k_chunks replaces k_setup below
   const bool vertex_setup = fs->d_draws != nullptr && !stats;
-  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, fs->d_frames, vertex_setup ? fs->d_bbox : nullptr, s);
+  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, fs->d_frames, vertex_setup ? fs->d_bbox : nullptr, fs->d_prep, s);
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in the rasteriser (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
@@ -401,7 +411,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     if (n != n_all) {
       v.frames += f0, v.n_frames = (uint32_t)n;
       v.vis += (size_t)f0 * fs->local_rows * (size_t)fs->width;
-      v.tile_cnt += (size_t)f0 * tpf, v.tile_off += (size_t)f0 * tpf;
+      v.tile_info += (size_t)f0 * tpf;
       v.out += (size_t)f0 * a.frame_stride;
       v.work_cap = (uint32_t)((size_t)(n < 8 ? n : (n + 7) / 8) * tpf);
     }
@@ -411,7 +421,6 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     else
       launch_setup(v, n, fs->max_tris, stats, s);
     launch_bin(v, n, fs->max_tris, s);
-    if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
     // the record pool's demand of this (sub-)render → host (word 0 of every allocator's line; one region per sub-batch).  No
     // event: the next render reads whatever has arrived (see the growth check above).  The latency build of k_raster stores it itself.
     auto copy_demand = [&](hipStream_t cs) {
@@ -419,6 +428,32 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       HIP_TRY(ctx, hipMemcpyAsync(dst, fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, hipMemcpyDeviceToHost, cs));
       return (int)SRZ_OK;
     };
+    // The FIRST render of a set sizes the pool by what it needs itself: it waits for k_bin's count, grows the pool if a band
+    // did not fit and bins again — a one-shot set (srz_draw_batch, the host layer's per-draw sets) has no second render that
+    // could profit from the lazy growth, and would otherwise leave its overflowing bands to the ordered rasteriser.
+    if (!fs->pool_sized && !stats) {
+      if (int rc = copy_demand(s)) return rc;
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      const uint32_t *dem = fs->h_pool_heads + (size_t)std::min(part, srz_frameset::DEMAND_PARTS - 1) * CNT_STRIDE * 64;
+      uint32_t need = 0;
+      for (uint32_t i = 0; i < fs->pool_n_sub; ++i) {
+        const uint32_t v = static_cast<const volatile uint32_t *>(dem)[i * CNT_STRIDE];
+        if (v > need) need = v;
+      }
+      if (need > fs->pool_sub_cap) {
+        HIP_TRY(ctx, hipDeviceSynchronize()); // (earlier sub-batches of this render may still be reading the old pool)
+        const uint64_t cap = (uint64_t)need + need / 8u + 64u;
+        if (cap * fs->pool_n_sub >= 0xffffffffull) return fail(ctx, SRZ_E_NOMEM, "tile lists exceed 2^32 records; split the batch");
+        uint32_t *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * cap * fs->pool_n_sub));
+        (void)hipFree(fs->d_pool);
+        fs->d_pool = p, fs->pool_sub_cap = (uint32_t)cap;
+        a.pool = v.pool = p, a.pool_sub_cap = v.pool_sub_cap = (uint32_t)cap;
+        HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, s));
+        launch_bin(v, n, fs->max_tris, s);
+      }
+    }
+    if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
     unsigned ev = 0;
     if (side) {
       ev = ctx->ev_next++ % srz_ctx::EV_RING;
@@ -440,6 +475,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     else if (!raster_four_waves(v))
       if (int rc = copy_demand(s)) return rc;
   }
+  if (!stats) fs->pool_sized = true;
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -602,7 +638,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     delete fs;
     return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: frames x tiles exceeds the launch grid limit; split the batch");
   }
-  uint64_t tri_off = 0, light_off = 0, batch_off = 0;
+  uint64_t tri_off = 0, light_off = 0, batch_off = 0, group_off = 0;
   for (int f = 0; f < n_frames; ++f) {
     const srz_frame &fr = frames[f];
     auto bad = [&](const char *m) {
@@ -633,11 +669,14 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     d.n_tris = (uint32_t)nt;
     d.n_local_bands = fs->n_local_bands;
     d.chunk_off = (uint32_t)(tri_off / 64u) + (uint32_t)f; // (every frame's chunk words start on a word of their own)
+    d.group_off = (uint32_t)group_off;
+    group_off += (nt + GROUP_TRIS - 1u) / GROUP_TRIS;
     fs->h_frames.push_back(d);
     fs->max_tris = std::max(fs->max_tris, d.n_tris);
     tri_off += nt, light_off += fr.n_lights, batch_off += fr.n_batches;
   }
-  fs->total_tris = tri_off, fs->total_lights = light_off;
+  fs->total_tris = tri_off, fs->total_lights = light_off, fs->total_groups = group_off;
+  fs->pool_sized = getenv("SRZ_POOL_LAZY") != nullptr; // (diagnostic / tests: no first-render sizing — the pool only follows the previous render's demand)
   classify_frames(fs);
 
   // stage host copies (pinned not needed: one-time upload)
@@ -664,6 +703,8 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(dev_alloc((void **)&fs->d_tris, sizeof(srz_tri) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_bbox, sizeof(BBox) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_chunk_rows, sizeof(uint32_t) * (tri_off / 64 + (size_t)n_frames + 1)));
+  FS_TRY(dev_alloc((void **)&fs->d_band_desc, sizeof(uint32_t) * group_off * fs->n_local_bands));
+  FS_TRY(dev_alloc((void **)&fs->d_band_ent, sizeof(uint2) * group_off * ENT_PER_GROUP));
   FS_TRY(dev_alloc((void **)&fs->d_tri_batch, sizeof(uint16_t) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_batches, sizeof(BatchDesc) * fs->h_batches.size()));
   FS_TRY(dev_alloc((void **)&fs->d_lights, sizeof(srz_light) * light_off));
@@ -676,14 +717,14 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     fs->pool_n_sub = n_sub;
     const uint64_t cap = std::min<uint64_t>((4ull * tri_off + 4096u) / n_sub + 64u, 0xfffffff0ull / n_sub);
     fs->pool_sub_cap = (uint32_t)cap;
-    FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(RasterRec) * cap * n_sub));
+    FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(uint32_t) * cap * n_sub));
+    FS_TRY(dev_alloc((void **)&fs->d_prep, sizeof(PrepTri) * tri_off));
     FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64)); // (one cache line per allocator)
     // what a render asked of each sub-pool comes back through pinned, device-mapped host memory: small jobs store it from
     // k_raster's first workgroup (no copy, no event, no query on the launch path), batches copy it on the clear's side stream
     FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64 * srz_frameset::DEMAND_PARTS, hipHostMallocMapped | hipHostMallocCoherent));
     if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * 64 * srz_frameset::DEMAND_PARTS);
-    FS_TRY(dev_alloc((void **)&fs->d_tile_cnt, sizeof(uint32_t) * fs->max_tiles));
-    FS_TRY(dev_alloc((void **)&fs->d_tile_off, sizeof(uint32_t) * fs->max_tiles));
+    FS_TRY(dev_alloc((void **)&fs->d_tile_info, sizeof(uint2) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_count, 2 * sizeof(uint32_t)));
     FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint32_t) * fs->max_tiles));

@@ -25,6 +25,18 @@ constexpr uint32_t CNT_STRIDE = 32;
 constexpr uint32_t FD_FAST_SHADE = 0x100u;
 constexpr uint32_t N_WORK_LISTS = 16;
 constexpr uint32_t UNLISTED = 0xffffffffu; // tile_off of a tile whose list did not fit the record pool
+// Binning is O(triangles): k_setup / k_chunks sort every GROUP of GROUP_TRIS (512) consecutive triangles by the 32-row bands their
+// bounding boxes reach (LDS count / scan / fill, no global atomics) into the group's own region of ENT_PER_GROUP 8-byte
+// entries {triangle, tile-x range}, and write one descriptor word per (group, local band): first entry << 16 | entries.
+// k_bin's (frame, band) workgroup then reads only its own entries.  A group whose entries do not fit the region (on average
+// more than 4 bands per triangle: huge triangles) gets DESC_RAW in every band, and the band workgroups walk that group's
+// bounding boxes themselves.
+#ifndef SRZ_GROUP_K
+#define SRZ_GROUP_K 2 // triangles per thread of a k_setup workgroup pass (measured 1 / 2 / 4: setup + bin 52 / 56 / 58 µs per 256 frames
+                      // of config 2, 106 / 99 / 104 µs per 32 frames of config 4)
+#endif
+constexpr uint32_t GROUP_K = SRZ_GROUP_K, GROUP_TRIS = 256u * GROUP_K, ENT_PER_GROUP = 4u * GROUP_TRIS, DESC_RAW = 0xffffffffu,
+                   MAX_LOCAL_BANDS = 1024;
 constexpr int MAX_TEX = 64;
 constexpr int MAX_MESH = 256;
 
@@ -34,17 +46,18 @@ struct __attribute__((aligned(8))) BBox {
   int16_t sx, sy, ex, ey;
 };
 
-// One entry of a TILE's triangle list: everything the coverage/z pass needs, gathered once by k_bin so that the tile
-// waves read their work with ONE level of coalesced loads (three 16-byte loads per entry).
-struct __attribute__((aligned(16))) RasterRec { // 48 bytes: three 16-byte loads
+// What the rasteriser needs of one kept triangle: screen-space positions + bounding box, 48 bytes = three 16-byte loads.
+// Written ONCE per triangle by k_setup (or k_vertex) at prep[triangle]; a TILE's list holds 4-byte triangle indices and the
+// tile's wave gathers the records through them (the lists used to hold whole 48-byte records: 12x the bytes per
+// (triangle, tile) pair, scattered stores that were half of k_bin's time).
+struct __attribute__((aligned(16))) PrepTri {
   float ax, ay, z0, bx, by, z1, cx, cy, z2;
   uint32_t bbx; // sx | sy << 16
   uint32_t bby; // ex | ey << 16
-  uint32_t idx; // triangle index inside the frame (= submission order)
+  uint32_t _pad;
 };
 // (the per-triangle constants of the coverage tests — 1 / fmsub(ABx,ACy,ACx*ABy) for the V columns, ABx*ACy - ABy*ACx for the
-// S columns — are recomputed by k_raster from the positions, once per record and 64 records at a time: 16 bytes less to
-// write and read back per (triangle, tile) pair)
+// S columns — are recomputed by k_raster from the positions, once per list entry and 64 entries at a time)
 
 // What the Shader object bound to a batch holds (type + texture), resolved on the host at render time
 struct __attribute__((aligned(8))) ShadeDescG {
@@ -75,6 +88,7 @@ struct FrameDesc {
   uint32_t flags;
   uint32_t n_local_bands;        // bands of this frame owned by this ctx
   uint32_t chunk_off;            // into chunk_rows[]: first 64-triangle chunk of this frame
+  uint32_t group_off;            // into band_desc[] / band_ent[]: first group (GROUP_TRIS triangles) of this frame
 };
 
 struct BatchDesc {
@@ -96,21 +110,24 @@ struct RenderArgs {
   const srz_tri *tris;
   const BBox *bbox;
   uint32_t *chunk_rows;          // per 64-triangle chunk: min sy | max ey << 16 of its kept triangles (k_setup → k_bands)
+  uint32_t *band_desc;           // [group][n_local_bands]: first entry << 16 | entries of the group in that band, or DESC_RAW
+  uint2 *band_ent;               // [group][ENT_PER_GROUP]: {triangle index in the frame, first tile x | last tile x << 16}
   const uint16_t *tri_batch;
   const BatchDesc *batches;
   const srz_light *lights;
   const TexDesc *tex;
   const ShadeDescG *sdesc;       // per batch (indexed like batches[])
-  // per-tile triangle lists, UNORDERED (the rasteriser's result does not depend on list order): records live in a pool
-  // of n_sub equal sub-pools with one bump allocator each; a (frame, band) workgroup of k_bin takes its band's records
+  PrepTri *prep;                 // [triangle] (indexed like tris[]): positions + bbox of the kept triangles
+  // per-tile triangle lists, UNORDERED (the rasteriser's result does not depend on list order): triangle indices in a pool
+  // of n_sub equal sub-pools with one bump allocator each; a (frame, band) workgroup of k_bin takes its band's entries
   // from sub-pool (workgroup id & sub_mask) in one allocation.  A band that does not fit is left UNLISTED: its tiles are
   // rasterised by k_raster_slow straight from the frame's stream, and the host grows the pool before the next render.
-  RasterRec *pool;
+  uint32_t *pool;
   uint32_t *pool_heads;          // [n_sub] records requested from each sub-pool by this render (zeroed by k_setup)
   uint32_t *pool_demand;         // pinned host memory laid out like pool_heads: what this render asked of each sub-pool (latency build of k_raster)
   uint32_t pool_sub_cap, pool_sub_mask;
-  uint32_t *tile_cnt;            // [frame][local band][tiles_x] entries in the tile's list (0: k_clear's tile)
-  uint32_t *tile_off;            // [frame][local band][tiles_x] first record in pool[], or UNLISTED
+  uint2 *tile_info;              // [frame][local band][tiles_x]: x = entries in the tile's list (0: k_clear's tile), y = its first
+                                 // index in pool[], or UNLISTED — one 8-byte load tells a tile's wave both
   uint32_t *slow_list;           // tiles (frame * tiles_per_frame + tile) left to the ordered rasteriser
   uint32_t *slow_count;
   uint32_t other_streams;        // host hint: the previous render of this ctx went to another stream (lanes): k_shade's grid follows
@@ -138,7 +155,7 @@ struct RenderArgs {
 };
 
 void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out,
-                   hipStream_t s);
+                   PrepTri *prep, hipStream_t s);
 void launch_chunks(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
 void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);

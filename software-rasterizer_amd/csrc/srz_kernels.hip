@@ -5,10 +5,12 @@
 // Not a translation of the AVX2 code: the reference walks triangles serially and rows in parallel; here
 //
 //   k_vertex  one thread per face          (optional) the vertex stage, Scene::loadTriangleStream: meshes + matrices → srz_tri
-//   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox record
-//   k_bin     one WORKGROUP per 32-row band count / scan / fill of the BBox stream into UNORDERED per-tile lists of 48-byte
-//                                          RasterRec (positions + bbox + index + the per-triangle constants of both coverage
-//                                          tests), LDS atomics only; records come from a pool sized by what renders need
+//   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox, the 48-byte PrepTri
+//                                          (positions + bbox) of every kept triangle, and — per group of 512 triangles, in
+//                                          LDS — the triangles sorted by the 32-row bands they reach: binning is O(triangles)
+//   k_bin     one WORKGROUP per 32-row band count / scan / fill of the band's own entries into UNORDERED per-tile lists of 4-byte
+//                                          triangle indices, LDS atomics only, assembled in LDS and stored as one coalesced run;
+//                                          the lists come from a pool sized by what renders need
 //   k_clear   ~64 persistent workgroups    on a second stream beside k_raster / k_shade: the fused clear of every tile no
 //                                          bbox reaches (16-byte non-temporal stores of +inf / 0), throttled by its grid
 //   k_raster  one WAVE per touched tile    VISIBILITY, order-independent: one 64-bit key (depth | tie-break) per pixel in
@@ -308,9 +310,19 @@ __device__ __forceinline__ bool setup_triangle(const float (&P)[9], int W, int H
   return keep;
 }
 
+// What the rasteriser needs of a kept triangle, written ONCE per triangle (48 bytes, coalesced) by the kernel that has its
+// positions in registers (k_setup, or k_vertex for scenesets); the tile lists hold 4-byte indices into this array.
+__device__ __forceinline__ void prep_store(PrepTri *dst, const float (&P)[9], const BBox &bb) {
+  const f32x4 q0 = {P[0], P[1], P[2], P[3]}, q1 = {P[4], P[5], P[6], P[7]};
+  const f32x4 q2 = {P[8], u2f_((uint32_t)(uint16_t)bb.sx | ((uint32_t)(uint16_t)bb.sy << 16)),
+                    u2f_((uint32_t)(uint16_t)bb.ex | ((uint32_t)(uint16_t)bb.ey << 16)), 0.0f};
+  f32x4 *o = reinterpret_cast<f32x4 *>(dst);
+  o[0] = q0, o[1] = q1, o[2] = q2;
+}
+
 // (bbox_out != null: the triangle's setup — cull + bounding box — is done here too, from the registers that hold it; k_chunks
 // then only reduces the boxes to the chunks' row ranges and the 96-byte triangles are not read back by a k_setup)
-__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out) {
+__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out, PrepTri *prep) {
   const SRZ_CAS DrawDesc *d = as_const(draws) + blockIdx.y;
   const uint32_t n_faces = d->n_faces;
   const SRZ_CAS srz_vertex *verts = as_const(d->verts);
@@ -334,73 +346,9 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
       const SRZ_CAS FrameDesc *fd = as_const(frames) + d->frame;
       const float P[9] = {t.pos[0][0], t.pos[0][1], t.pos[0][2], t.pos[1][0], t.pos[1][1], t.pos[1][2], t.pos[2][0], t.pos[2][1], t.pos[2][2]};
       BBox bb;
-      (void)setup_triangle(P, fd->width, fd->height, fd->eye[0], fd->eye[1], fd->eye[2], true, bb);
+      if (setup_triangle(P, fd->width, fd->height, fd->eye[0], fd->eye[1], fd->eye[2], true, bb)) prep_store(prep + d->tri_off + f, P, bb);
       bbox_out[d->tri_off + f] = bb;
     }
-  }
-}
-
-// ================================================================================================================
-// k_setup — per triangle: finite check, bbox, backface test (src/Triangle.cpp:147-151,243-257; Rasterizer.cpp:203)
-// ================================================================================================================
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
-  if (blockIdx.x == 0 && blockIdx.y == 0) { // the work lists, k_shade's cursors into them, the record pool and the slow list start empty
-    if (threadIdx.x < N_WORK_LISTS) a.work_count[threadIdx.x * CNT_STRIDE] = 0u, a.work_count[threadIdx.x * CNT_STRIDE + 1] = 0u;
-    if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x * CNT_STRIDE] = 0u;
-    if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
-  }
-  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
-  const int W = fd->width, H = fd->height;
-  const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
-  const float ex = fd->eye[0], ey = fd->eye[1], ez = fd->eye[2];
-  unsigned long long n_culled = 0, tests = 0;
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; (t & ~63u) < n_tris; t += gridDim.x * 256) { // whole waves
-    const bool live = t < n_tris;
-    const SRZ_CAS float *p = as_const(&a.tris[tri_off + (live ? t : 0u)].pos[0][0]);
-    const float P[9] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
-    BBox bb;
-    const bool keep = setup_triangle(P, W, H, ex, ey, ez, live, bb);
-    if (STATS) {
-      if (keep)
-        tests += (unsigned long long)(bb.ex - bb.sx + 1) * (unsigned long long)(bb.ey - bb.sy + 1);
-      else if (live)
-        n_culled++;
-    }
-    if (live) bbox_out[tri_off + t] = bb;
-    // rows spanned by the kept triangles of this 64-triangle chunk (= this wave's 64 consecutive t): lets k_bin skip
-    // the chunks that cannot reach a band without reading their 64 bboxes
-    int lo = keep ? (int)bb.sy : 0x7fff, hi = keep ? (int)bb.ey : -1;
-    for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));
-    if ((threadIdx.x & 63) == 0) a.chunk_rows[fd->chunk_off + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
-  }
-  if (STATS) {
-    if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
-    if (tests) atomicAdd(&a.stats[ST_PIXEL_TESTS], tests);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[ST_TRIS], (unsigned long long)n_tris);
-  }
-}
-
-// k_chunks — scenesets: k_vertex has written the bounding boxes; what is left of k_setup is the reset of the per-render
-// counters and the row range of every 64-triangle chunk (8 bytes read per triangle instead of 96)
-__global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
-    if (threadIdx.x < N_WORK_LISTS) a.work_count[threadIdx.x * CNT_STRIDE] = 0u, a.work_count[threadIdx.x * CNT_STRIDE + 1] = 0u;
-    if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x * CNT_STRIDE] = 0u;
-    if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
-  }
-  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
-  const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
-  const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + tri_off));
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; (t & ~63u) < n_tris; t += gridDim.x * 256) { // whole waves
-    int lo = 0x7fff, hi = -1;
-    if (t < n_tris) {
-      const u32x2 r = bbox[t];
-      const int sx = (int16_t)(r.x & 0xffff), sy = (int16_t)(r.x >> 16), ex = (int16_t)(r.y & 0xffff), ey = (int16_t)(r.y >> 16);
-      if (sx <= ex) lo = sy, hi = ey; // (the empty box of a culled triangle: sx > ex)
-    }
-    for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));
-    if ((threadIdx.x & 63) == 0) a.chunk_rows[fd->chunk_off + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
   }
 }
 
@@ -425,27 +373,182 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 }
 
 // ================================================================================================================
+// bucket_group — the O(triangles) half of the binning, shared by k_setup and k_chunks: the GROUP_TRIS triangles of one group
+// (GROUP_K per thread: triangle g * GROUP_TRIS + k * 256 + tid) are sorted by the local 32-row bands their bounding boxes reach, in LDS:
+//   count  one LDS atomic per (triangle, band)             scan  exclusive prefix over the bands (wave 0, DPP)
+//   fill   a second LDS atomic hands out the slots; the entry {triangle, tile-x range} goes to the group's own region
+// and the group's descriptor row [band] = first entry << 16 | entries.  No global atomics, no cross-workgroup state.
+// A group that needs more than ENT_PER_GROUP entries (or holds a triangle more than 64 local bands tall) is marked
+// DESC_RAW in every band instead: k_bin's band workgroups then walk its bounding boxes themselves.
+// ================================================================================================================
+__device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t nlb, const uint32_t group, const uint32_t t0,
+                                             const BBox (&bb)[GROUP_K], const bool (&keep)[GROUP_K], uint32_t *s_cnt, uint32_t *s_off,
+                                             uint32_t *s_fill, uint32_t *s_misc) {
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int world = a.shard_world, rank = a.shard_rank;
+  for (uint32_t i = (uint32_t)tid; i < nlb; i += 256u) s_cnt[i] = 0u;
+  if (tid == 0) s_misc[0] = 0u;
+  __syncthreads();
+  // the local bands of triangle k: lb0[k] .. lb0[k] + nb[k] - 1 (band b is local iff b % world == rank; local index b / world)
+  int lb0[GROUP_K], nb[GROUP_K];
+#pragma unroll
+  for (int k = 0; k < (int)GROUP_K; ++k) {
+    lb0[k] = 0, nb[k] = 0;
+    if (keep[k]) {
+      const int b0 = (int)bb[k].sy >> 5, b1 = (int)bb[k].ey >> 5;
+      const int first = b0 + ((rank - b0) % world + world) % world;
+      if (first <= b1) lb0[k] = first / world, nb[k] = (b1 - first) / world + 1;
+      if (nb[k] > 64) s_misc[0] = 1u, nb[k] = 0; // (benign race: every writer stores 1)
+      for (int j = 0; j < nb[k]; ++j) atomicAdd(&s_cnt[lb0[k] + j], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < nlb; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane, v = i < nlb ? s_cnt[i] : 0u, incl = wave_scan_add(v);
+      if (i < nlb) s_off[i] = s_fill[i] = run + incl - v;
+      run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0 && run > ENT_PER_GROUP) s_misc[0] = 1u;
+  }
+  __syncthreads();
+  const bool raw = s_misc[0] != 0u;
+  uint32_t *desc = a.band_desc + (size_t)group * nlb;
+  for (uint32_t i = (uint32_t)tid; i < nlb; i += 256u) desc[i] = raw ? DESC_RAW : ((s_off[i] << 16) | s_cnt[i]);
+  if (!raw) {
+    uint2 *ent = a.band_ent + (size_t)group * ENT_PER_GROUP;
+#pragma unroll
+    for (int k = 0; k < (int)GROUP_K; ++k) {
+      const uint32_t xr = (uint32_t)((int)bb[k].sx >> 5) | ((uint32_t)((int)bb[k].ex >> 5) << 16);
+      for (int j = 0; j < nb[k]; ++j) ent[atomicAdd(&s_fill[lb0[k] + j], 1u)] = make_uint2(t0 + (uint32_t)k * 256u + (uint32_t)tid, xr);
+    }
+  }
+  __syncthreads(); // (LDS is reused by this workgroup's next group)
+}
+
+// row range of the kept triangles of a 64-triangle chunk (= one wave's 64 consecutive triangles): k_raster_slow and the
+// DESC_RAW walk of k_bin skip the chunks that cannot reach their rows without reading the 64 bounding boxes
+__device__ __forceinline__ void chunk_rows_store(const RenderArgs &a, const uint32_t chunk_off, const uint32_t t, const uint32_t n_tris,
+                                                 const bool keep, const BBox &bb) {
+  int lo = keep ? (int)bb.sy : 0x7fff, hi = keep ? (int)bb.ey : -1;
+  for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));
+  if ((threadIdx.x & 63) == 0 && (t & ~63u) < n_tris) a.chunk_rows[chunk_off + t / 64u] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}
+
+__device__ __forceinline__ void reset_render_counters(const RenderArgs &a) {
+  // the work lists, k_shade's cursors into them, the record pool and the slow list start empty
+  if (threadIdx.x < N_WORK_LISTS) a.work_count[threadIdx.x * CNT_STRIDE] = 0u, a.work_count[threadIdx.x * CNT_STRIDE + 1] = 0u;
+  if (threadIdx.x <= a.pool_sub_mask) a.pool_heads[threadIdx.x * CNT_STRIDE] = 0u;
+  if (threadIdx.x == 0) *a.slow_count = 0u, *a.redo_count = 0u;
+}
+
+// ================================================================================================================
+// k_setup — per triangle: finite check, bbox, backface test (src/Triangle.cpp:147-151,243-257; Rasterizer.cpp:203);
+// per group of GROUP_TRIS triangles (one workgroup pass, GROUP_K triangles per thread): the band sort above
+// ================================================================================================================
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
+  __shared__ uint32_t s_cnt[MAX_LOCAL_BANDS], s_off[MAX_LOCAL_BANDS], s_fill[MAX_LOCAL_BANDS], s_misc[2];
+  if (blockIdx.x == 0 && blockIdx.y == 0) reset_render_counters(a);
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
+  const int W = fd->width, H = fd->height;
+  const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
+  const float ex = fd->eye[0], ey = fd->eye[1], ez = fd->eye[2];
+  unsigned long long n_culled = 0, tests = 0;
+  const uint32_t n_groups = (n_tris + GROUP_TRIS - 1u) / GROUP_TRIS;
+  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const uint32_t t0 = g * GROUP_TRIS;
+    float P[GROUP_K][9];
+#pragma unroll
+    for (int k = 0; k < (int)GROUP_K; ++k) { // (all the loads of the thread's triangles in flight together)
+      const uint32_t t = t0 + (uint32_t)k * 256u + threadIdx.x;
+      const SRZ_CAS float *p = as_const(&a.tris[tri_off + (t < n_tris ? t : 0u)].pos[0][0]);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) P[k][i] = p[i];
+    }
+    BBox bb[GROUP_K];
+    bool keep[GROUP_K];
+#pragma unroll
+    for (int k = 0; k < (int)GROUP_K; ++k) {
+      const uint32_t t = t0 + (uint32_t)k * 256u + threadIdx.x;
+      const bool live = t < n_tris;
+      keep[k] = setup_triangle(P[k], W, H, ex, ey, ez, live, bb[k]);
+      if (STATS) {
+        if (keep[k])
+          tests += (unsigned long long)(bb[k].ex - bb[k].sx + 1) * (unsigned long long)(bb[k].ey - bb[k].sy + 1);
+        else if (live)
+          n_culled++;
+      }
+      if (live) bbox_out[tri_off + t] = bb[k];
+      if (keep[k]) prep_store(a.prep + tri_off + t, P[k], bb[k]);
+      chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
+    }
+    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, s_cnt, s_off, s_fill, s_misc);
+  }
+  if (STATS) {
+    if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
+    if (tests) atomicAdd(&a.stats[ST_PIXEL_TESTS], tests);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[ST_TRIS], (unsigned long long)n_tris);
+  }
+}
+
+// k_chunks — scenesets: k_vertex has written the bounding boxes; what is left of k_setup is the reset of the per-render
+// counters, the row range of every 64-triangle chunk and the band sort (8 bytes read per triangle instead of 96)
+__global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
+  __shared__ uint32_t s_cnt[MAX_LOCAL_BANDS], s_off[MAX_LOCAL_BANDS], s_fill[MAX_LOCAL_BANDS], s_misc[2];
+  if (blockIdx.x == 0 && blockIdx.y == 0) reset_render_counters(a);
+  const SRZ_CAS FrameDesc *fd = as_const(a.frames) + blockIdx.y;
+  const uint32_t n_tris = fd->n_tris, tri_off = fd->tri_off;
+  const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + tri_off));
+  const uint32_t n_groups = (n_tris + GROUP_TRIS - 1u) / GROUP_TRIS;
+  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const uint32_t t0 = g * GROUP_TRIS;
+    BBox bb[GROUP_K];
+    bool keep[GROUP_K];
+#pragma unroll
+    for (int k = 0; k < (int)GROUP_K; ++k) {
+      const uint32_t t = t0 + (uint32_t)k * 256u + threadIdx.x;
+      bb[k].sx = 1, bb[k].sy = 1, bb[k].ex = 0, bb[k].ey = 0;
+      if (t < n_tris) {
+        const u32x2 r = bbox[t];
+        bb[k].sx = (int16_t)(r.x & 0xffff), bb[k].sy = (int16_t)(r.x >> 16), bb[k].ex = (int16_t)(r.y & 0xffff), bb[k].ey = (int16_t)(r.y >> 16);
+      }
+      keep[k] = bb[k].sx <= bb[k].ex; // (the empty box of a culled triangle: sx > ex)
+      chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
+    }
+    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, s_cnt, s_off, s_fill, s_misc);
+  }
+}
+
+// ================================================================================================================
 // k_bin — one WORKGROUP per (frame, local band): the triangles whose bbox touches the band are appended to the lists
 // of the 32x32 tiles they overlap.  The rasteriser's result does not depend on the order of a tile's list (k_raster
 // resolves depth ties with the triangle index, not with the list position), so this is a plain count / scan / fill with
 // LDS atomics — no ordered compaction:
-//   pass 1  the 64-triangle chunks are dealt to the waves; a chunk whose row range (written by k_setup) misses the band
-//           is skipped without reading its bboxes; every hit bumps the LDS counter of each tile it overlaps
+//   input   the band's entries, sorted out by k_setup / k_chunks (bucket_group): per group of GROUP_TRIS triangles one descriptor
+//           word (first entry, entries) — 64 groups per wave load — whose entry runs are flattened into dense batches of
+//           64 (the triangles that start inside a batch mark their position, a DPP max-scan gives every lane its group,
+//           its descriptor comes over the LDS crossbar): the walk reads 8 bytes per (triangle, band) pair, nothing else.
+//           Groups marked DESC_RAW (huge triangles) are walked the old way: chunk row ranges, then bounding boxes.
+//   pass 1  every entry bumps the LDS counter of each tile it overlaps
 //   scan    exclusive prefix over the tile counters (wave 0) = the band's layout; ONE global atomic takes the band's
 //           records from the sub-pool of this workgroup (k_raster_slow serves the tiles of a band that does not fit)
-//   pass 2  the hits are queued per wave and flushed 64 at a time: one round trip of independent gathers (positions +
-//           bbox) per 64 hits, the per-triangle constants of both coverage tests are computed once here, and every
-//           (triangle, tile) pair becomes one 48-byte record at pool[band base + tile offset + slot]
+//   pass 2  every (triangle, tile) pair becomes one 4-byte index at pool[band base + tile offset + slot]: assembled in LDS,
+//           written as one coalesced run (k_raster gathers the triangles' 48-byte PrepTri records, written once per triangle
+//           by k_setup / k_vertex, through these indices)
 // ================================================================================================================
 constexpr int BIN_MAX_WAVES = 8; // launched with 2, 4 or 8 waves: the walk is latency-bound, so short streams take small
                                  // workgroups (more of them resident per CU), long ones more waves per band
-// dynamic LDS = (3 * tiles_x + 128 * waves + 4) dwords: [count | offset | fill cursor] per tile, per-wave queues
+constexpr uint32_t BIN_STAGE = 4096; // indices of one band staged in LDS (16 KB)
+// dynamic LDS = (3 * tiles_x + 64 * waves + 4 + BIN_STAGE) dwords: [count | offset | fill cursor] per tile, per-wave marks, stage
 __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   const int BIN_WAVES = (int)(blockDim.x >> 6);
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   const uint32_t TX = a.tiles_x;
-  uint32_t *s_cnt = s_dyn, *s_off = s_dyn + TX, *s_fill = s_dyn + 2 * TX, *s_q = s_dyn + 3 * TX;
-  uint32_t *s_misc = s_q + 128 * BIN_WAVES; // [0] first record of the band in pool[] (or UNLISTED), [1] records of the band
+  uint32_t *s_cnt = s_dyn, *s_off = s_dyn + TX, *s_fill = s_dyn + 2 * TX, *s_marks = s_dyn + 3 * TX;
+  uint32_t *s_misc = s_marks + 64 * BIN_WAVES; // [0] first index of the band in pool[] (or UNLISTED), [1] indices of the band
+  uint32_t *s_stage = s_misc + 4;
   // same XCD-aware decomposition as k_raster: workgroup i bins frame (i % 8) of its group of 8 frames, so a frame's
   // records are written through the L2 of the XCD that will rasterise it
   const uint32_t wg = blockIdx.x, xcd = wg & 7u, jj = wg >> 3;
@@ -455,48 +558,90 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (uint32_t w = threadIdx.x; w < 3 * TX; w += blockDim.x) s_dyn[w] = 0u;
+  uint32_t *s_mark = s_marks + 64 * wave;
+  s_mark[lane] = 0u;
   __syncthreads();
   const uint32_t n_tris = fd->n_tris;
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
   const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
-  const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
   const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->chunk_off;
-  const uint32_t n_chunks = (n_tris + 63) / 64;
-  uint32_t *qi = s_q + 128 * wave;
-  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint32_t n_chunks = (n_tris + 63) / 64, n_groups = (n_tris + GROUP_TRIS - 1u) / GROUP_TRIS;
+  const uint32_t nlb = a.n_local_bands;
+  const SRZ_CAS uint32_t *desc = as_const(a.band_desc) + (size_t)fd->group_off * nlb + lb;
+  const SRZ_CAS u32x2 *ents = reinterpret_cast<const SRZ_CAS u32x2 *>(as_const(a.band_ent) + (size_t)fd->group_off * ENT_PER_GROUP);
 
-  // walks the chunks of this wave and calls fn(chunk, hit, bbox words) for every chunk that can reach the band, with the
-  // bbox loads of four candidate chunks in flight together (the walk is latency-bound, not bandwidth-bound)
+  // a DESC_RAW group: its 16 chunks' row ranges, then the bounding boxes of the chunks that can reach the band, the loads of
+  // four candidate chunks in flight together
+  auto walk_raw = [&](const uint32_t g, auto &&fn) {
+    const uint32_t c0 = g * (GROUP_TRIS / 64u);
+    bool cand = false;
+    const uint32_t c = c0 + (uint32_t)lane;
+    if (lane < (int)(GROUP_TRIS / 64u) && c < n_chunks) {
+      const uint32_t r = chunk_rows[c];
+      cand = (int)(int16_t)(r & 0xffffu) <= y1 && (int)(int16_t)(r >> 16) >= y0;
+    }
+    unsigned long long mc = __ballot(cand);
+    while (mc) {
+      uint32_t cj[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ok[u] = mc != 0ull;
+        cj[u] = ok[u] ? (uint32_t)__builtin_ctzll(mc) : 0u;
+        mc &= mc - 1ull; // (0 stays 0)
+      }
+      u32x2 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = bbox[min((c0 + cj[u]) * 64u + (uint32_t)lane, n_tris - 1u)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) break; // wave-uniform
+        const uint32_t t = (c0 + cj[u]) * 64u + (uint32_t)lane;
+        const int sx = (int16_t)(r[u].x & 0xffff), sy = (int16_t)(r[u].x >> 16), ex = (int16_t)(r[u].y & 0xffff), ey = (int16_t)(r[u].y >> 16);
+        fn(t, t < n_tris && sx <= ex && sy <= y1 && ey >= y0, sx >> 5, ex >> 5); // (bbox is clamped to the frame by k_setup)
+      }
+    }
+  };
+  // calls fn(triangle, hit, first tile x, last tile x) wave-wide for every triangle of the frame that reaches the band: every wave
+  // reads the descriptors of all groups (64 per round) and takes every BIN_WAVES-th batch of 64 entries, continuing round-robin
+  // across the rounds, so the entries of a frame with few groups are still spread over all the waves
   auto walk = [&](auto &&fn) {
-    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_chunks; c0 += 64u * (uint32_t)BIN_WAVES) {
-      bool cand = false;
-      const uint32_t c = c0 + (uint32_t)lane;
-      if (c < n_chunks) {
-        const uint32_t r = chunk_rows[c];
-        cand = (int)(int16_t)(r & 0xffffu) <= y1 && (int)(int16_t)(r >> 16) >= y0;
+    const uint32_t NW = (uint32_t)BIN_WAVES;
+    uint32_t first = (uint32_t)wave; // the first batch of the next round that is this wave's
+    for (uint32_t r0 = 0; r0 < n_groups; r0 += 64u) {
+      const uint32_t g = r0 + (uint32_t)lane;
+      const uint32_t d = g < n_groups ? desc[(size_t)g * nlb] : 0u;
+      const bool raw = d == DESC_RAW;
+      const uint32_t cnt = raw ? 0u : (d & 0xffffu), off = d >> 16;
+      const uint32_t incl = wave_scan_add(cnt), excl = incl - cnt;
+      const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), nbat = (T + 63u) >> 6;
+      uint32_t b = first;
+      for (; b < nbat; b += NW) {
+        const uint32_t P0 = b * 64u;
+        // the group that reaches into this batch from before it: the last one that starts before P0
+        const unsigned long long before = __ballot(cnt != 0u && excl < P0);
+        const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+        const uint32_t r = excl - P0;
+        if (cnt != 0u && r < 64u) s_mark[r] = (uint32_t)lane + 1u;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t m = s_mark[lane];
+        __builtin_amdgcn_wave_barrier();
+        s_mark[lane] = 0u;
+        m = max(wave_scan_max(m), carry);
+        const uint32_t sl = (m - 1u) & 63u; // the lane that holds this entry's group
+        const uint32_t e_excl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)sl * 4, (int)excl);
+        const uint32_t e_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)sl * 4, (int)off);
+        const uint32_t e = P0 + (uint32_t)lane;
+        const bool valid = e < T;
+        u32x2 en = {0u, 0u};
+        if (valid) en = ents[(size_t)(r0 + sl) * ENT_PER_GROUP + e_off + (e - e_excl)];
+        fn(en.x, valid, (int)(en.y & 0xffffu), (int)(en.y >> 16));
       }
-      unsigned long long mc = __ballot(cand);
-      while (mc) {
-        uint32_t cj[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          ok[u] = mc != 0ull;
-          cj[u] = ok[u] ? (uint32_t)__builtin_ctzll(mc) : 0u;
-          mc &= mc - 1ull; // (0 stays 0)
-        }
-        u32x2 r[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = bbox[min((c0 + cj[u]) * 64u + (uint32_t)lane, n_tris - 1u)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (!ok[u]) break; // wave-uniform
-          const uint32_t t = (c0 + cj[u]) * 64u + (uint32_t)lane;
-          const int sx = (int16_t)(r[u].x & 0xffff), sy = (int16_t)(r[u].x >> 16), ex = (int16_t)(r[u].y & 0xffff), ey = (int16_t)(r[u].y >> 16);
-          fn(t, t < n_tris && sx <= ex && sy <= y1 && ey >= y0, sx >> 5, ex >> 5); // (bbox is clamped to the frame by k_setup)
-        }
-      }
+      first = b - nbat; // (b is the first batch index >= nbat that is this wave's: b - nbat < NW)
+      uint32_t ri = 0;  // DESC_RAW groups of the round: dealt to the waves one by one
+      for (unsigned long long mr = __ballot(raw); mr != 0ull; mr &= mr - 1ull, ++ri)
+        if (ri % NW == (uint32_t)wave) walk_raw(r0 + (uint32_t)__builtin_ctzll(mr), fn);
     }
   };
   // ---- pass 1: tile counts ---------------------------------------------------------------------------------------------
@@ -528,48 +673,31 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   __syncthreads();
   const uint32_t base = s_misc[0];
   {
-    uint32_t *tc = a.tile_cnt + ((size_t)frame * a.n_local_bands + lb) * TX, *to = a.tile_off + ((size_t)frame * a.n_local_bands + lb) * TX;
-    for (uint32_t tx = threadIdx.x; tx < TX; tx += blockDim.x) tc[tx] = s_cnt[tx], to[tx] = base == UNLISTED ? UNLISTED : base + s_off[tx];
+    uint2 *ti = a.tile_info + ((size_t)frame * a.n_local_bands + lb) * TX;
+    for (uint32_t tx = threadIdx.x; tx < TX; tx += blockDim.x) ti[tx] = make_uint2(s_cnt[tx], base == UNLISTED ? UNLISTED : base + s_off[tx]);
   }
   if (base == UNLISTED || s_misc[1] == 0u) return; // workgroup-uniform
   // ---- pass 2: fill ------------------------------------------------------------------------------------------------------
-  RasterRec *out = a.pool + base;
-  auto flush = [&](uint32_t n) { // n <= 64 queued triangles → one record per (triangle, tile) pair
-    if ((uint32_t)lane < n) {
-      const uint32_t t = qi[lane];
-      const u32x2 r = bbox[t];
-      const SRZ_CAS float *p = &tris[t].pos[0][0];
-      TriXY k;
-      k.ax = p[0], k.ay = p[1], k.z0 = p[2], k.bx = p[3], k.by = p[4], k.z1 = p[5], k.cx = p[6], k.cy = p[7], k.z2 = p[8];
-      const f32x4 q0 = {k.ax, k.ay, k.z0, k.bx}, q1 = {k.by, k.z1, k.cx, k.cy};
-      const f32x4 q2 = {k.z2, u2f_(r.x), u2f_(r.y), u2f_(t)};
-      const int tlo = (int)(int16_t)(r.x & 0xffff) >> 5, thi = (int)(int16_t)(r.y & 0xffff) >> 5;
+  // The band's lists hold 4-byte triangle indices (the rasteriser gathers the 48-byte PrepTri of an index itself): they are
+  // assembled in LDS — slots handed out by LDS atomics, tile after tile — and leave as ONE run of coalesced stores.  A band
+  // with more pairs than the stage holds stores its indices straight into the pool.
+  uint32_t *out = a.pool + base;
+  const uint32_t run = s_misc[1];
+  const bool staged = run <= BIN_STAGE; // workgroup-uniform
+  walk([&](uint32_t t, bool hit, int tlo, int thi) {
+    if (hit)
       for (int tx = tlo; tx <= thi; ++tx) {
-        f32x4 *o = reinterpret_cast<f32x4 *>(out + s_off[tx] + atomicAdd(&s_fill[tx], 1u));
-        o[0] = q0, o[1] = q1, o[2] = q2;
+        const uint32_t slot = s_off[tx] + atomicAdd(&s_fill[tx], 1u);
+        if (staged)
+          s_stage[slot] = t;
+        else
+          out[slot] = t;
       }
-    }
-  };
-  uint32_t nq = 0;
-  walk([&](uint32_t t, bool hit, int, int) {
-    const unsigned long long m = __ballot(hit);
-    if (m == 0ull) return;
-    if (hit) qi[nq + (uint32_t)__popcll(m & lt)] = t;
-    nq += (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    if (nq >= 64) {
-      flush(64);
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t rest = nq - 64; // < 64
-      uint32_t mi = 0;
-      if ((uint32_t)lane < rest) mi = qi[64 + lane];
-      __builtin_amdgcn_wave_barrier();
-      if ((uint32_t)lane < rest) qi[lane] = mi;
-      nq = rest;
-      __builtin_amdgcn_wave_barrier();
-    }
   });
-  if (nq) flush(nq);
+  if (staged) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < run; i += blockDim.x) out[i] = s_stage[i];
+  }
 }
 
 // ================================================================================================================
@@ -1054,7 +1182,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   if (frame >= a.n_frames) return;
   // nothing listed for this tile: nothing to rasterise; its clear (if any) is k_clear's job — or, in a small job that has
   // no k_clear beside it (one kernel boundary less on the latency path), this wave's
-  const uint32_t cnt = as_const(a.tile_cnt)[(size_t)frame * tiles_per_frame + tile];
+  const u32x2 tinfo = as_const(reinterpret_cast<const u32x2 *>(a.tile_info))[(size_t)frame * tiles_per_frame + tile];
+  const uint32_t cnt = tinfo.x;
   if (cnt == 0u && !a.clear_in_raster) return; // (three tiles in four of a batch: out after ONE load)
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
   const uint32_t flags = fd->flags | a.flags_or;
@@ -1083,7 +1212,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     }
     return;
   }
-  const uint32_t off = as_const(a.tile_off)[(size_t)frame * tiles_per_frame + tile];
+  const uint32_t off = tinfo.y;
   if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
     if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
@@ -1099,6 +1228,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
   uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
 
+  // (the first 64 indices of the tile's list are loaded under the tile init)
+  const uint32_t i_first = as_const(a.pool)[off + min((uint32_t)lane, cnt - 1u)];
   // ---- phase A: tile init (fused clear → +inf, else the in/out z plane) with the incoming-depth tie-break ----------
   for (int i = (int)threadIdx.x; i < TILE * TILE; i += 64 * WAVES) {
     const int ly = i >> 5, lx = i & 31;
@@ -1125,7 +1256,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     float zmin;            // nearest vertex depth
   };
   auto geometry = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, bool valid) {
-    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby idx | r3 = v_inv s_area
+    // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby -
     const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z);
     const int bsx = (int16_t)(bbx & 0xffff), bsy = (int16_t)(bbx >> 16), bex = (int16_t)(bby & 0xffff), bey = (int16_t)(bby >> 16);
     const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
@@ -1139,7 +1270,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     g.zmin = __builtin_fminf(__builtin_fminf(r0.z, r1.y), r2.x);
     return g;
   };
-  const SRZ_CAS f32x4 *recs = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.pool) + off);
+  const SRZ_CAS uint32_t *list = as_const(a.pool) + off; // the tile's triangle indices
+  const SRZ_CAS f32x4 *prep = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.prep) + fd->tri_off);
   // ---- depth-ordered groups for chunks with heavy overdraw -----------------------------------------------------------
   // The keys make the order of the triangles irrelevant, so a chunk of records that asks for several times the tile's area in
   // pixel tests is rasterised NEAREST FIRST, in 4 groups of equal depth range of the triangles' nearest vertex (the records
@@ -1153,14 +1285,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   //            never dropped
   uint32_t zfar = 0xffffffffu; // image of the tile's farthest depth when last read back (all ones: nothing can be dropped yet;
                                // depths only come down, so an old value stays a valid bound)
+  // two-deep pipeline: the indices of chunk c + 2 and the records of chunk c + 1 are in flight while chunk c is rasterised
   f32x4 n0, n1, n2;
   bool nv = (uint32_t)lane < cnt;
-  {
-    const uint32_t e = nv ? (uint32_t)lane : 0u;
-    n0 = recs[3 * e], n1 = recs[3 * e + 1], n2 = recs[3 * e + 2];
-  }
+  uint32_t i_cur = i_first, i_nxt = 64u < cnt ? list[min(64u + (uint32_t)lane, cnt - 1u)] : 0u;
+  n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
   for (uint32_t base = 0; base < cnt; base += 64) {
     const f32x4 r0 = n0, r1 = n1, r2 = n2;
+    const uint32_t my_idx = i_cur;
     // the per-triangle constants of the two coverage tests, once per record (a record carries 48 bytes, not these 8 more)
     float rec_v_inv, rec_s_area;
     {
@@ -1172,11 +1304,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     }
     const bool valid = nv;
     nv = base + 64 + lane < cnt;
-    if (base + 64 < cnt) { // the next chunk is in flight while this one is rasterised
-      const uint32_t e = nv ? base + 64 + lane : base;
-      n0 = recs[3 * e], n1 = recs[3 * e + 1], n2 = recs[3 * e + 2];
+    if (base + 64 < cnt) {
+      i_cur = i_nxt;
+      n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
+      if (base + 128 < cnt) i_nxt = list[min(base + 128u + (uint32_t)lane, cnt - 1u)];
     }
-    const uint32_t my_idx = f2u(r2.w);
     const Geo G = geometry(r0, r1, r2, valid);
     const uint32_t geom = G.word;
     uint32_t group = 0, n_groups = 1, znear = 0, znear_s = 0; // nearest possible depth of a V / S fragment, as keys (0: unknown → kept)
@@ -1627,9 +1759,9 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
     const int rows = min(BAND, H - band * BAND);
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W;
-    const SRZ_CAS uint32_t *cnt = as_const(a.tile_cnt) + (size_t)br * a.tiles_x;
+    const SRZ_CAS u32x2 *cnt = as_const(reinterpret_cast<const u32x2 *>(a.tile_info)) + (size_t)br * a.tiles_x;
     for (int x4 = (int)threadIdx.x * 4; x4 < W; x4 += 256 * 4) {
-      if (cnt[(uint32_t)x4 / TILE] != 0u) continue; // some bbox reaches this tile: the rasteriser's
+      if (cnt[(uint32_t)x4 / TILE].x != 0u) continue; // some bbox reaches this tile: the rasteriser's
       if (((W & 3) == 0)) {
         for (int ly = 0; ly < rows; ++ly) {
           float *g = base + (size_t)ly * W + x4;
@@ -2046,23 +2178,23 @@ __global__ void k_tex_convert(const uint8_t *bgr, int w, int h, int row_stride, 
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
 void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out,
-                   hipStream_t s) {
+                   PrepTri *prep, hipStream_t s) {
   if (n_draws == 0 || max_faces == 0) return;
   dim3 grid((max_faces + 255) / 256, n_draws);
   if (grid.x > 1024) grid.x = 1024;
-  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris, frames, bbox_out);
+  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris, frames, bbox_out, prep);
 }
 
 void launch_chunks(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s) {
   if (n_frames <= 0 || max_tris == 0) return;
-  dim3 grid((max_tris + 255) / 256, n_frames);
+  dim3 grid((max_tris + GROUP_TRIS - 1u) / GROUP_TRIS, n_frames); // one workgroup pass per group
   if (grid.x > 4096) grid.x = 4096;
   hipLaunchKernelGGL(k_chunks, grid, dim3(256), 0, s, a);
 }
 
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s) {
   if (n_frames <= 0 || max_tris == 0) return;
-  dim3 grid((max_tris + 255) / 256, n_frames);
+  dim3 grid((max_tris + GROUP_TRIS - 1u) / GROUP_TRIS, n_frames); // one workgroup pass per group
   if (grid.x > 4096) grid.x = 4096;
   BBox *bb = const_cast<BBox *>(a.bbox);
   if (stats)
@@ -2077,7 +2209,7 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
   static const int env = getenv("SRZ_BIN_WAVES") ? atoi(getenv("SRZ_BIN_WAVES")) : 0;
   // (measured: 4 waves best at 5.9 k triangles, 8 at 94 k; a job with fewer band workgroups than CUs is pure latency: 8)
   const int waves = env ? env : ((max_tris <= 32768u && (uint32_t)n_frames * a.n_local_bands > 256u) ? 4 : BIN_MAX_WAVES);
-  const size_t lds = sizeof(uint32_t) * (3u * (size_t)a.tiles_x + 128u * waves + 4u);
+  const size_t lds = sizeof(uint32_t) * (3u * (size_t)a.tiles_x + 64u * waves + 4u + BIN_STAGE);
   hipLaunchKernelGGL(k_bin, dim3(groups * 8u * a.n_local_bands), dim3(64 * waves), lds, s, a);
 }
 

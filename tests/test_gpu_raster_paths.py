@@ -106,10 +106,11 @@ def test_unified_flag_both_paths(ctx, orc):
     both_paths(ctx, orc, lambda extra: frame(t, 128, 96, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | abi.UNIFIED | extra), what="unified")
 
 
-def test_pool_overflow_then_growth(ctx, orc):
-    """A few screen-filling triangles make far more (triangle, tile) pairs than the first guess of the record pool: the
-    first render serves the bands that do not fit through the ordered rasteriser, the next one finds the pool grown.
-    Both must equal the oracle."""
+def test_pool_overflow_then_growth(ctx, orc, monkeypatch):
+    """A few screen-filling triangles make far more (triangle, tile) pairs than the first guess of the list pool.  With the
+    first-render sizing switched off (SRZ_POOL_LAZY, read when the set is created) the first render serves the bands that do
+    not fit through the ordered rasteriser and the next one finds the pool grown.  Both must equal the oracle."""
+    monkeypatch.setenv("SRZ_POOL_LAZY", "1")
     w = h = 1024
     n = 24
     t = np.zeros(n, abi.TRI_DTYPE)
@@ -144,3 +145,57 @@ def test_many_small_frames_fill_every_subpool(ctx, orc):
         rc, ref, _ = orc.draw(frames[i])
         same(got[i], ref, f"frame {i}")
     fs.close()
+
+
+def big_tris(n, w, h, seed, tall):
+    """n triangles about `tall` pixels high at random places (depths distinct per triangle)"""
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, abi.TRI_DTYPE)
+    cx, cy = rng.uniform(0, w, n), rng.uniform(0, h, n)
+    t["pos"][:, 0, :2] = np.stack([cx - 9, cy - tall / 2], 1)
+    t["pos"][:, 2, :2] = np.stack([cx + 11, cy - tall / 2 + 3], 1)  # (this winding faces the eye at (0, 0, 1))
+    t["pos"][:, 1, :2] = np.stack([cx + 2, cy + tall / 2], 1)
+    t["pos"][:, :, 2] = rng.uniform(5, 50, (n, 1))
+    nn = rng.normal(size=(n, 3, 3))
+    t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+    return t
+
+
+def test_first_render_sizes_the_pool(ctx, orc):
+    """the same screen-filling triangles WITHOUT the lazy switch: a one-shot set must come out of the order-independent
+    rasteriser on its first (and only) render — no tile may be left to the ordered one for want of pool space"""
+    w = h = 1024
+    n = 24
+    t = np.zeros(n, abi.TRI_DTYPE)
+    for i in range(n):
+        t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
+    t["nrm"][:] = [0, 0, -1]
+    f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
+    rc, ref, _ = orc.draw(f)
+    planes, _ = ctx.draw_batch([f])
+    same(planes[0], ref, "one-shot draw_batch")
+
+
+@pytest.mark.parametrize("tall,n", [(150, 700), (2300, 40)])
+def test_groups_with_huge_triangles_take_the_raw_walk(ctx, orc, tall, n):
+    """a 512-triangle group whose triangles reach more bands than its entry region holds (700 triangles x 5-6 bands), and
+    triangles taller than 64 bands: k_setup marks the group DESC_RAW and k_bin's band workgroups walk its bounding boxes"""
+    w, h = 160, 2400
+    t = big_tris(n, w, h, 11, tall)
+    both_paths(ctx, orc, lambda extra: frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | extra), what=f"raw groups tall={tall}")
+
+
+def test_band_with_more_pairs_than_the_lds_stage(ctx, orc):
+    """6000 small triangles in ONE 32-row band of a wide frame: the band's index list (> 4096 entries) does not fit k_bin's LDS
+    stage and is stored straight into the pool"""
+    w, h = 2048, 64
+    rng = np.random.default_rng(3)
+    n = 6000
+    t = np.zeros(n, abi.TRI_DTYPE)
+    cx, cy = rng.uniform(4, w - 4, n), rng.uniform(3, 28, n)
+    t["pos"][:, 0, :2] = np.stack([cx - 3, cy - 2], 1)
+    t["pos"][:, 2, :2] = np.stack([cx + 4, cy - 1], 1)
+    t["pos"][:, 1, :2] = np.stack([cx, cy + 3], 1)
+    t["pos"][:, :, 2] = rng.uniform(5, 50, (n, 1))
+    t["nrm"][:] = [0, 0, -1]
+    both_paths(ctx, orc, lambda extra: frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | extra), what="stage overflow")

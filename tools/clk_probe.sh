@@ -4,7 +4,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/clk_$2
 rm -rf $O; mkdir -p $O
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/g -- python3 tests/perf_probe.py $1 6 > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/g -- python3 tools/perf_probe.py $1 6 > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
 python3 - "$O" <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]

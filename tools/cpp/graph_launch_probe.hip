@@ -1,5 +1,5 @@
 // dev probe: host cost and end-to-end time of 7 small dependent kernels, launched one by one vs replayed as a hipGraph.
-// Build: hipcc --offload-arch=gfx950 -O3 -o build/graph_launch tests/cpp/graph_launch_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o build/graph_launch tools/cpp/graph_launch_probe.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

@@ -2,7 +2,7 @@
 //   rows   a wave-instruction stores 1 KiB of ONE framebuffer row (k_clear's pattern), workgroup = one 32-row band
 //   tiles  a wave-instruction stores 8 rows x 128 B of one 32x32 tile (k_shade / k_raster write-out), workgroup = one tile
 //   tilesW the same for tiles 64 / 128 pixels wide (256 / 512-byte pieces)
-// Build: hipcc --offload-arch=gfx950 -O3 -o build/store_pattern tests/cpp/store_pattern_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o build/store_pattern tools/cpp/store_pattern_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // dev probe: the wave-level primitives k_raster / k_bin rely on (DPP scans, ds_bpermute, ds_min_u64), checked against
-// host code.  Build: hipcc --offload-arch=gfx950 -O3 -o build/wave_prims tests/cpp/wave_prims_probe.hip
+// host code.  Build: hipcc --offload-arch=gfx950 -O3 -o build/wave_prims tools/cpp/wave_prims_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

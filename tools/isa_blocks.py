@@ -1,7 +1,7 @@
 """Dev tool: per-basic-block instruction mix of one kernel from the -save-temps assembly (make -C software-rasterizer_amd asm).
-usage: python tests/isa_blocks.py <mangled-substring> [--dump LABEL]"""
+usage: python tools/isa_blocks.py <mangled-substring> [--dump LABEL]"""
 import re, sys
-s = open(__file__.rsplit('/tests/', 1)[0] + '/software-rasterizer_amd/build/srz_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+s = open(__file__.rsplit('/tools/', 1)[0] + '/software-rasterizer_amd/build/srz_kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read()
 key = sys.argv[1]
 m = re.search(r'^(_Z\w*' + re.escape(key) + r'\w*):', s, re.M)
 i = m.start(); j = s.index('.Lfunc_end', i)

@@ -1,5 +1,5 @@
 """Dev tool (not a test, not the bench): time the frameset path on the GPU for a config.
-usage: python tests/perf_probe.py [config=2] [frames=64] [iters=20]"""
+usage: python tools/perf_probe.py [config=2] [frames=64] [iters=20]"""
 import os
 import sys
 import time

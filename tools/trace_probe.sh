@@ -1,10 +1,10 @@
 #!/bin/bash
-# Dev tool, run ON THE GPU BOX: per-kernel durations of tests/perf_probe.py (usage: bash tests/trace_probe.sh "2 256" tag)
+# Dev tool, run ON THE GPU BOX: per-kernel durations of tools/perf_probe.py (usage: bash tools/trace_probe.sh "2 256" tag)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/trace_$2
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -- python3 tests/perf_probe.py $1 10 > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -- python3 tools/perf_probe.py $1 10 > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
 tail -2 $O/run.log
 python3 - "$O" <<'PY'
 import csv, glob, sys
