@@ -206,6 +206,114 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     return dt, kt, per_step
 
 
+def make_comm(ctx, dist, torch, rank, world):
+    """The exchange's RCCL communicator behind the C ABI (srz_comm_create), decided COLLECTIVELY: ncclCommInitRank is a
+    collective, so a rank must not enter it unless every rank will, and all ranks must end up on the same exchange path.
+      1. rank-local: can this rank load librccl and make an id at all?  (srz_comm_unique_id — no communication)
+      2. all-reduce(MIN) of that flag over torch.distributed: one failure → nobody calls srz_comm_create
+      3. rank 0's id is broadcast, every rank calls srz_comm_create
+      4. all-reduce(MIN) of the results: one failure → every rank drops its communicator and all exchange through
+         torch.distributed's RCCL instead (+ the HIP de-interleave)
+    → (comm or None, note or None)"""
+    import srz
+    err = None
+    try:
+        my_id = srz.Comm.unique_id()
+    except Exception as e:  # noqa: BLE001
+        my_id, err = None, f"librccl not usable on rank {rank}: {e}"
+    ok = torch.tensor([1 if my_id is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 0:
+        return None, (err or "librccl not usable on some rank") + "; exchange through torch.distributed instead"
+    ids = [my_id if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    comm = None
+    try:
+        comm = srz.Comm(ctx, ids[0], rank, world)
+    except Exception as e:  # noqa: BLE001
+        err = f"srz_comm_create failed on rank {rank}: {e}"
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 0:
+        if comm is not None:
+            comm.close()
+        return None, (err or "srz_comm_create failed on some rank") + "; exchange through torch.distributed instead"
+    return comm, None
+
+
+def time_multi_gpu(case, comm, dist, steps, warmup, fence, exchange="planes", no_overlap=False):
+    """N > 1 (also runs at world 1 with a one-rank communicator — tests/test_gpu_exchange.py drives it there, so the scaling
+    run is not this code's first execution): render on one stream, exchange (all-gather + de-interleave) on another,
+    double-buffered: the exchange of step k runs while step k+1 renders.  → (dt, kernel times, per-step list, multi dict)"""
+    from srz import abi, parallel
+    torch, ctx, fs, world = case.torch, case.ctx, case.fs, case.world
+    what = abi.EXCHANGE_PLANES if exchange == "planes" else abi.EXCHANGE_BGR8
+    bpr = fs.local_rows // 32 if world > 1 else None
+    rows_full = bpr * world * 32 if world > 1 else fs.local_rows
+    if exchange == "planes":
+        shard = case.out
+        full_shape, dtype = (case.n_frames, 4, rows_full, fs.width), torch.float32
+    else:  # display()'s 8-bit image: one "plane" of W*3 bytes per row
+        shard = [torch.empty((case.n_frames, 1, fs.local_rows, fs.width * 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        full_shape, dtype = (case.n_frames, 1, rows_full, fs.width * 3), torch.uint8
+    gathered = [torch.empty((world,) + tuple(shard[0].shape), dtype=dtype, device="cuda") for _ in range(2)]
+    full = [torch.empty(full_shape, dtype=dtype, device="cuda") for _ in range(2)]
+    rq = parallel.TorchQueue()
+    xq = rq if no_overlap else parallel.TorchQueue()
+
+    def render(b):
+        fs.render(case.out[b].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, rq.handle)
+        if exchange == "bgr8":
+            fs.resolve8(case.out[b].data_ptr(), shard[b].data_ptr(), shard[b].numel(), rq.handle)
+
+    def do_exchange(b):
+        if comm is not None:
+            fs.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
+        else:  # (torch.distributed's RCCL on the current = exchange stream, then the HIP de-interleave)
+            dist.all_gather_into_tensor(gathered[b].view(-1), shard[b].reshape(-1))
+            fs.deinterleave(gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
+
+    pipe = parallel.ExchangePipeline(render, do_exchange, rq, xq)
+    for _ in range(warmup):
+        pipe.step()
+    pipe.drain()
+    fence()
+    ctx.set_kernel_timing(2)  # (per-kernel split: the exchange dominates an N > 1 step, two more events do not matter)
+    ctx.kernel_time_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step()
+    pipe.drain()
+    fence()
+    dt = time.perf_counter() - t0
+    kt = ctx.kernel_time_ms(reset=True)
+    ctx.set_kernel_timing(False)
+    # the exchange alone (no render beside it), same buffers: what the overlap has to hide
+    fence()
+    t1 = time.perf_counter()
+    for k in range(steps):
+        xq.submit(lambda b=k % 2: do_exchange(b))
+    xq.drain()
+    fence()
+    x_alone = (time.perf_counter() - t1) / steps * 1e3
+    if dist is not None:
+        tt = torch.tensor([dt, x_alone * 1e-3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, x_alone = float(tt[0]), float(tt[1]) * 1e3
+    step_ms = dt / steps * 1e3
+    shard_bytes = shard[0].numel() * shard[0].element_size()
+    multi = {"exchange": exchange, "behind_c_abi": comm is not None, "overlapped": not no_overlap,
+             "step_ms": step_ms, "render_ms_per_step": kt["total_ms"], "exchange_alone_ms_per_step": x_alone,
+             "hidden_ms_per_step": max(0.0, kt["total_ms"] + x_alone - step_ms),
+             "bytes_sent_per_rank_per_step": shard_bytes, "bytes_received_per_rank_per_step": (world - 1) * shard_bytes,
+             "predicted_exchange_ms_at_xgmi_peak": shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3,
+             "note": "exchange = srz_frameset_allgather: ncclAllGather of every rank's band shard (each rank sends its shard "
+                     "once to each of the N-1 peers, one xGMI link per peer: time >= shard bytes / 153 GB/s) + one HIP "
+                     "de-interleave pass; step k's exchange runs while step k+1 renders",
+             "last_full": full[(steps - 1) % 2]}
+    return dt, kt, [], multi
+
+
 def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
     fs = case.fs
     fps = case.n_frames * steps / dt
@@ -278,14 +386,7 @@ def main():
             torch.cuda.synchronize()
 
     ctx = srz.Context(local_rank, rank, world)
-    comm, comm_note = None, None
-    if world > 1:  # the exchange behind the C ABI: RCCL communicator from an id made on rank 0
-        try:
-            ids = [srz.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = srz.Comm(ctx, ids[0], rank, world)
-        except Exception as e:  # noqa: BLE001  (fall back to torch.distributed's RCCL rather than lose the measurement)
-            comm, comm_note = None, f"srz_comm_create failed ({e}); exchange through torch.distributed instead"
+    comm, comm_note = (None, None) if world == 1 else make_comm(ctx, dist, torch, rank, world)
 
     case = Case(ctx, torch, args.workload, args.frames, args.scope, world, n_out=2 if world > 1 else 1)
     fs, stats = case.fs, case.stats
@@ -300,69 +401,9 @@ def main():
     if world == 1:
         dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes)
     else:
-        # ---- N > 1: render on one stream, exchange (all-gather + de-interleave) on another, double-buffered ------------
-        what = abi.EXCHANGE_PLANES if args.exchange == "planes" else abi.EXCHANGE_BGR8
-        bpr = fs.local_rows // 32
-        if args.exchange == "planes":
-            shard = case.out
-            full_shape, dtype = (case.n_frames, 4, bpr * world * 32, fs.width), torch.float32
-        else:  # display()'s 8-bit image: one "plane" of W*3 bytes per row
-            shard = [torch.empty((case.n_frames, 1, fs.local_rows, fs.width * 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            full_shape, dtype = (case.n_frames, 1, bpr * world * 32, fs.width * 3), torch.uint8
-        gathered = [torch.empty((world,) + tuple(shard[0].shape), dtype=dtype, device="cuda") for _ in range(2)]
-        full = [torch.empty(full_shape, dtype=dtype, device="cuda") for _ in range(2)]
-        rq = parallel.TorchQueue()
-        xq = rq if args.no_overlap else parallel.TorchQueue()
-
-        def render(b):
-            fs.render(case.out[b].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, rq.handle)
-            if args.exchange == "bgr8":
-                fs.resolve8(case.out[b].data_ptr(), shard[b].data_ptr(), shard[b].numel(), rq.handle)
-
-        def exchange(b):
-            if comm is not None:
-                fs.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
-            else:  # (torch.distributed's RCCL on the current = exchange stream, then the HIP de-interleave)
-                dist.all_gather_into_tensor(gathered[b].view(-1), shard[b].reshape(-1))
-                fs.deinterleave(gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
-
-        pipe = parallel.ExchangePipeline(render, exchange, rq, xq)
-        for _ in range(args.warmup):
-            pipe.step()
-        pipe.drain()
-        fence()
-        ctx.set_kernel_timing(2)  # (per-kernel split: the exchange dominates an N > 1 step, two more events do not matter)
-        ctx.kernel_time_ms(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.step()
-        pipe.drain()
-        fence()
-        dt = time.perf_counter() - t0
-        kt = ctx.kernel_time_ms(reset=True)
-        ctx.set_kernel_timing(False)
-        per_step = []
-        # the exchange alone (no render beside it), same buffers: what the overlap has to hide
-        fence()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            xq.submit(lambda b=k % 2: exchange(b))
-        xq.drain()
-        fence()
-        x_alone = (time.perf_counter() - t1) / args.steps * 1e3
-        tt = torch.tensor([dt, x_alone * 1e-3], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, x_alone = float(tt[0]), float(tt[1]) * 1e3
-        step_ms = dt / args.steps * 1e3
-        shard_bytes = shard[0].numel() * shard[0].element_size()
-        multi = {"exchange": args.exchange, "behind_c_abi": comm is not None, "overlapped": not args.no_overlap,
-                 "step_ms": step_ms, "render_ms_per_step": kt["total_ms"], "exchange_alone_ms_per_step": x_alone,
-                 "hidden_ms_per_step": max(0.0, kt["total_ms"] + x_alone - step_ms),
-                 "bytes_sent_per_rank_per_step": shard_bytes, "bytes_received_per_rank_per_step": (world - 1) * shard_bytes,
-                 "predicted_exchange_ms_at_xgmi_peak": shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3,
-                 "note": "exchange = srz_frameset_allgather: ncclAllGather of every rank's band shard (each rank sends its shard "
-                         "once to each of the N-1 peers, one xGMI link per peer: time >= shard bytes / 153 GB/s) + one HIP "
-                         "de-interleave pass; step k's exchange runs while step k+1 renders"}
+        dt, kt, per_step, multi = time_multi_gpu(case, comm, dist if world > 1 else None, args.steps, args.warmup, fence, args.exchange,
+                                                 args.no_overlap)
+        multi.pop("last_full")
         if comm_note:
             multi["fallback"] = comm_note
 

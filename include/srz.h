@@ -30,7 +30,15 @@
 extern "C" {
 #endif
 
-#define SRZ_ABI_VERSION 2
+/* Bumped whenever an entry point is added, a struct changes or an argument changes its meaning; every binding compares it
+ * with srz_abi_version() when it loads the library and refuses a mismatch (srz/__init__.py: ImportError; libsrz_host.so:
+ * std::runtime_error from the TraditionalRasterizer constructor).
+ *   1  round 1
+ *   2  srz_draw_batch, scenesets, targets
+ *   3  `stream` arguments: NULL = the ctx's own stream, SRZ_STREAM_NULL = HIP's null stream (was: NULL = null stream);
+ *      srz_comm_*, srz_frameset_allgather / _deinterleave / _exchange_bytes, srz_kernel_time_samples
+ */
+#define SRZ_ABI_VERSION 3
 
 /* error codes */
 #define SRZ_OK 0

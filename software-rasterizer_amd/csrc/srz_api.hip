@@ -55,6 +55,10 @@ struct srz_ctx {
   srz_frameset *draw_fs = nullptr;
   float *draw_out = nullptr;
   std::vector<uint64_t> draw_sig;
+  // diagnostic switches, read ONCE when the ctx is created (never per render): frames per sub-batch of a large set (0: the
+  // default below), 32-bit owner ids even where 16 would do
+  int env_sub_batch = 0;
+  bool env_no_vis16 = false;
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
   hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
@@ -235,8 +239,7 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.force_ordered = 0, a.force_generic = 0, a.any_generic = fs->any_generic ? 1u : 0u;
   a.sdesc = fs->d_sdesc;
   a.vis = fs->d_vis;
-  static const bool no_vis16 = getenv("SRZ_NO_VIS16") != nullptr; // (A/B of the owner-id width)
-  a.vis16 = (!no_vis16 && fs->max_tris < 32768u) ? 1u : 0u;
+  a.vis16 = (!ctx->env_no_vis16 && fs->max_tris < 32768u) ? 1u : 0u;
   a.worklist = fs->d_worklist;
   a.work_count = fs->d_work_count;
   // (a list holds the tiles of every 8th frame; of fewer than 8 frames: any of them)
@@ -340,6 +343,9 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   RenderArgs a = make_args(ctx, fs, d_out, flags_or);
   if (one_frame_scratch) a.frame_stride = 0;
   a.force_ordered = a.force_generic = stats ? 1u : 0u; // the counters are those of the reference's ordered walk
+  a.any_ordered = ((flags_or & SRZ_ORDERED_RASTER) != 0 ||
+                   std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_ORDERED_RASTER) != 0; }))
+                      ? 1u : 0u;
   EventPair ep{};
   const bool timed = ctx->timing != 0 && !stats && ctx->ev_used.size() < 65536, detailed = timed && ctx->timing >= 2;
   if (timed) {
@@ -396,7 +402,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // The sub-batch size is 192 frames' worth of 1024^2 (≈ 197 k tiles: the measured sweet spot), in frames of THIS set — a
   // rank of an 8-GPU job holds an eighth of every frame and takes 1536 of them at a time; frames so large that fewer than 64
   // make a sub-batch are left alone (nothing of theirs fits the cache either way).
-  const int sub_env = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0; // (tuning / tests: frames per sub-batch; read per render)
+  const int sub_env = ctx->env_sub_batch; // (tuning / tests: frames per sub-batch)
   const size_t tiles_per_frame = std::max<size_t>((size_t)fs->n_local_bands * fs->tiles_x, 1);
   const int sub = sub_env > 0 ? sub_env : (int)std::min<size_t>((192u * 1024u / tiles_per_frame + 7u) / 8u * 8u, 1u << 20);
   if (sub >= 64 && n_all >= sub + sub / 2 + 32 && !stats && !detailed) {
@@ -461,8 +467,10 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       hipStream_t side_s = ctx->stream2;
       HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
       launch_clear(v, tiles, true, side_s);
+      // (in front of the join: whatever follows on the launch stream — the next sub-batch's or render's k_setup zeroes the
+      // allocators — is ordered behind this copy; it is 16 words behind a kernel that outlasts k_raster)
+      if (int rc = copy_demand(side_s)) return rc;
       HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
-      if (int rc = copy_demand(side_s)) return rc; // (behind the join: off the critical path)
     }
     launch_raster(v, n, stats, s);
     if (turns) {
@@ -536,6 +544,8 @@ int srz_create(srz_ctx **out, int device_id) {
   srz_ctx *ctx = new (std::nothrow) srz_ctx();
   if (!ctx) return fail(nullptr, SRZ_E_NOMEM, "srz_create: out of host memory");
   ctx->device = device_id;
+  ctx->env_sub_batch = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0;
+  ctx->env_no_vis16 = getenv("SRZ_NO_VIS16") != nullptr;
   for (int i = 0; i < MAX_TEX; ++i) ctx->h_tex[i] = TexDesc{nullptr, 0, 0}, ctx->d_texmem[i] = nullptr;
   auto bail = [&](const char *what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
@@ -1016,8 +1026,10 @@ int srz_target_read_bgr8(srz_ctx *ctx, srz_target *t, uint8_t *bgr8) {
 void srz_frameset_destroy(srz_ctx *ctx, srz_frameset *fs) {
   if (!fs) return;
   if (ctx) {
+    // renders of this set may still be running on the ctx's stream, on the clear's side stream or on a stream the caller
+    // passed to srz_frameset_render: wait for the whole device before its buffers (and the pinned demand words) go
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
   }
   free_frameset_buffers(fs);
   delete fs;

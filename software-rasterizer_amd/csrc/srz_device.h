@@ -133,6 +133,7 @@ struct RenderArgs {
   uint32_t other_streams;        // host hint: the previous render of this ctx went to another stream (lanes): k_shade's grid follows
   uint32_t clear_in_raster;      // small jobs: no k_clear is launched, k_raster's waves clear the tiles no bbox reaches
   uint32_t force_ordered;        // every touched tile goes to k_raster_slow (SRZ_ORDERED_RASTER, counting runs)
+  uint32_t any_ordered;          // host hint: SRZ_ORDERED_RASTER is set on the render or on some frame (k_raster_slow gets a large grid)
   uint32_t force_generic;        // every frame is shaded by the generic build of k_shade (counting runs)
   uint32_t any_generic;          // some frame is not FD_FAST_SHADE (else the generic build only serves redo_list)
   uint32_t *redo_list;           // tiles (frame * tiles_per_frame + tile) the FAST build of k_shade hands to the generic one

@@ -511,6 +511,10 @@ void RenderingPipeline::display(Primitive type) {
 TraditionalRasterizer::TraditionalRasterizer() : RenderingPipeline() { init(); }
 TraditionalRasterizer::TraditionalRasterizer(std::size_t width, std::size_t height) : RenderingPipeline(width, height) { init(); }
 void TraditionalRasterizer::init() {
+  // the host layer is compiled against include/srz.h: a libsrz.so of another ABI version (stale build, LD_LIBRARY_PATH) is refused
+  if (srz_abi_version() != SRZ_ABI_VERSION)
+    throw std::runtime_error("TraditionalRasterizer: libsrz.so reports SRZ_ABI_VERSION " + std::to_string(srz_abi_version()) +
+                             ", libsrz_host.so was built against " + std::to_string(SRZ_ABI_VERSION) + " — rebuild both");
   int dev = 0;
   if (const char *e = std::getenv("SRZ_DEVICE")) dev = std::atoi(e);
   int rc = srz_create(&m_ctx, dev);

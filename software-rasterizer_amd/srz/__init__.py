@@ -36,6 +36,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found — the HIP extension is not built and there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
+        # a binding and a library that disagree on the ABI (a stale build, SRZ_LIB_PATH pointing at another checkout) must not
+        # get as far as a call: argument MEANINGS change between versions (v3: the stream sentinel), not only signatures
+        L.srz_abi_version.restype = C.c_int
+        got = L.srz_abi_version()
+        if got != abi.SRZ_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} reports SRZ_ABI_VERSION {got}, this binding is written against {abi.SRZ_ABI_VERSION}: "
+                              "rebuild the library (python -c 'import __graft_entry__ as g; g.build()') or fix SRZ_LIB_PATH")
         fp, vp = C.POINTER(C.c_float), C.c_void_p
         L.srz_create.argtypes = [C.POINTER(vp), C.c_int]
         L.srz_destroy.argtypes = [vp]

@@ -2,6 +2,8 @@
 
 Mirrors shard_layout() in csrc/srz_api.hip.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in
 the CPU tests)."""
+from . import abi
+
 BAND = 32
 
 
@@ -181,8 +183,9 @@ class LaneRenderer:
     def out_shape(self):
         return (self.n_frames, 4, self.local_rows, self.width)
 
-    def render(self, d_out_ptr, flags=1):
-        """one batch: every lane renders its frames into its part of out, asynchronously, on its own stream"""
+    def render(self, d_out_ptr, flags=abi.FUSED_CLEAR):
+        """one batch: every lane renders its frames into its part of out, asynchronously, on its own stream.  flags as
+        FrameSet.render: the default treats the buffer as just cleared (write-only); 0 = accumulate onto what out holds"""
         for k, fs in enumerate(self.sets):
             fs.render(d_out_ptr + self.cuts[k] * self.frame_bytes, fs.out_bytes, flags, self.streams[k].cuda_stream)
 

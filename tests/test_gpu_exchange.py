@@ -85,6 +85,90 @@ def test_communicator_of_one_rank(orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("exchange", ["planes", "bgr8"])
+def test_bench_multi_gpu_step_loop_at_world_one(orc, exchange):
+    """bench.py's N > 1 branch (render stream + exchange stream, double-buffered ExchangePipeline, srz_frameset_allgather
+    through a real RCCL communicator, the exchange-alone pass) driven at world 1, so that the 8-GPU scaling run is not that
+    code's first execution; the last step's full frames must be the oracle's."""
+    import bench
+    import srz
+    ctx = srz.Context(0)
+    comm = srz.Comm(ctx, srz.Comm.unique_id(), 0, 1)
+    case = bench.Case(ctx, torch, "spot_texture_1024", 6, "raster", 1, n_out=2)
+    for slot, tex in enumerate(scenes_textures(case)):
+        orc.texture_set(slot, tex)
+
+    def fence():
+        torch.cuda.synchronize()
+
+    dt, kt, per_step, multi = bench.time_multi_gpu(case, comm, None, steps=3, warmup=2, fence=fence, exchange=exchange)
+    assert dt > 0 and kt["launches"] == 3 and multi["behind_c_abi"] and multi["overlapped"]
+    assert multi["bytes_sent_per_rank_per_step"] == case.fs.exchange_bytes(abi.EXCHANGE_PLANES if exchange == "planes" else abi.EXCHANGE_BGR8)
+    full = multi.pop("last_full").cpu().numpy()
+    import json
+    json.dumps(multi)  # (what is left goes into bench.py's JSON line)
+    for i in (0, 5):
+        ref = orc.draw(case.frames[i])[1]
+        if exchange == "planes":
+            assert np.array_equal(bits(full[i]), bits(np.stack(ref)))
+        else:
+            assert np.array_equal(full[i, 0].reshape(1024, 1024, 3), orc.resolve8(tuple(ref)))
+    case.close()
+    comm.close()
+    ctx.close()
+
+
+def scenes_textures(case):
+    from srz import scenes as pscenes
+    wl = pscenes.WORKLOADS[case.name]()
+    wl.frame(0)
+    return wl.texture_arrays
+
+
+@pytest.mark.parametrize("cfg,frames_idx", [(4, (3,)), (5, (3,))])
+def test_baseline_configs_4_and_5_as_specified_eight_way_sharded(orc, cfg, frames_idx):
+    """BASELINE configs 4 (spot x16, 2048^2, TEXTURE) and 5 (8 depth-stacked spots, 4096^2, NORMAL + PHONG) AS SPECIFIED:
+    every frame's 32-row bands dealt to 8 ranks.  One GPU plays every rank in turn; the stacked shards are what the all-gather
+    leaves, and srz_frameset_deinterleave of them must be the oracle's full frames bit for bit — float planes and display()'s
+    8-bit image."""
+    import srz
+    world = 8
+    build = {4: scenes.config4, 5: scenes.config5}[cfg]
+    frames = [build(i) for i in frames_idx]
+    size = frames[0].width
+    refs = [np.stack(orc.draw(f)[1]) for f in frames]
+    lay = parallel.shard_layout(size, 0, world)
+    gathered = torch.empty((world, len(frames), 4, lay["local_rows"], size), dtype=torch.float32, device="cuda")
+    g8 = torch.empty((world, len(frames), 1, lay["local_rows"], size * 3), dtype=torch.uint8, device="cuda")
+    keep = None
+    for r in range(world):
+        ctx = srz.Context(0, r, world)
+        ctx.texture_upload(0, scenes.spot_texture())
+        fs = ctx.frameset(frames)
+        assert fs.local_rows == lay["local_rows"]
+        s = torch.cuda.current_stream().cuda_stream
+        fs.render(gathered[r].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
+        fs.resolve8(gathered[r].data_ptr(), g8[r].data_ptr(), g8[r].numel(), s)
+        torch.cuda.synchronize()
+        if r == 0:
+            keep = (ctx, fs)
+        else:
+            fs.close(), ctx.close()
+    ctx, fs = keep
+    rows = lay["bands_per_rank"] * world * 32
+    full = torch.empty((len(frames), 4, rows, size), dtype=torch.float32, device="cuda")
+    full8 = torch.empty((len(frames), 1, rows, size * 3), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    fs.deinterleave(gathered.data_ptr(), full.data_ptr(), abi.EXCHANGE_PLANES, s)
+    fs.deinterleave(g8.data_ptr(), full8.data_ptr(), abi.EXCHANGE_BGR8, s)
+    torch.cuda.synchronize()
+    for i in range(len(frames)):
+        got = full[i, :, :size].cpu().numpy()
+        assert np.array_equal(bits(got), bits(refs[i])), (cfg, i)
+        assert np.array_equal(full8[i, 0, :size].cpu().numpy().reshape(size, size, 3), orc.resolve8(tuple(refs[i]))), (cfg, i)
+    fs.close(), ctx.close()
+
+
 def test_render_on_the_null_stream_is_ordered(orc):
     """stream 0 (torch's default stream) must mean the NULL stream, not the context's private non-blocking stream: a torch
     op queued right after the render has to see its result."""
@@ -114,40 +198,44 @@ def _two_rank_worker(rank, world, port, q):
     torch.cuda.set_device(rank)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # (rendezvous only: the exchange is srz_comm's RCCL)
     try:
-        oracle.texture_set(0, scenes.spot_texture())
-        ctx = srz.Context(rank, rank, world)
-        ctx.texture_upload(0, scenes.spot_texture())
-        ids = [srz.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = srz.Comm(ctx, ids[0], rank, world)
-        size, nf, steps = 256, 3, 5
-        sets = [ctx.frameset([scenes.config2(3 * k + i, size=size) for i in range(nf)]) for k in range(steps)]
-        fs0 = sets[0]
-        bpr = fs0.local_rows // 32
-        shard = [torch.zeros(fs0.out_shape, dtype=torch.float32, device="cuda") for _ in range(2)]
-        gathered = [torch.empty((world,) + tuple(fs0.out_shape), dtype=torch.float32, device="cuda") for _ in range(2)]
-        full = [torch.empty((nf, 4, bpr * world * 32, size), dtype=torch.float32, device="cuda") for _ in range(2)]
-        rq, xq = parallel.TorchQueue(), parallel.TorchQueue()
-        state = {"k": 0}
-        pipe = parallel.ExchangePipeline(
-            lambda b: sets[state["k"]].render(shard[b].data_ptr(), fs0.out_bytes, abi.FUSED_CLEAR, rq.handle),
-            lambda b: fs0.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), abi.EXCHANGE_PLANES, xq.handle),
-            rq, xq)
-        ok, snaps = True, []
-        for k in range(steps):   # a different set of frames every step: a torn or stale buffer cannot go unnoticed
-            state["k"] = k
-            b = pipe.step()
-            with torch.cuda.stream(xq.stream):
-                snaps.append(full[b].clone())
-        pipe.drain()
-        torch.cuda.synchronize()
-        for k in range(steps):
-            got = snaps[k].cpu().numpy()[:, :, :size]
-            for i in range(nf):
-                ref = np.stack(oracle.draw(scenes.config2(3 * k + i, size=size))[1])
-                ok = ok and np.array_equal(got[i].view(np.uint32), ref.view(np.uint32))
-        q.put((rank, ok))
-        comm.close()
+      try:
+          oracle.texture_set(0, scenes.spot_texture())
+          ctx = srz.Context(rank, rank, world)
+          ctx.texture_upload(0, scenes.spot_texture())
+          ids = [srz.Comm.unique_id() if rank == 0 else None]
+          dist.broadcast_object_list(ids, src=0)
+          comm = srz.Comm(ctx, ids[0], rank, world)
+          size, nf, steps = 256, 3, 5
+          sets = [ctx.frameset([scenes.config2(3 * k + i, size=size) for i in range(nf)]) for k in range(steps)]
+          fs0 = sets[0]
+          bpr = fs0.local_rows // 32
+          shard = [torch.zeros(fs0.out_shape, dtype=torch.float32, device="cuda") for _ in range(2)]
+          gathered = [torch.empty((world,) + tuple(fs0.out_shape), dtype=torch.float32, device="cuda") for _ in range(2)]
+          full = [torch.empty((nf, 4, bpr * world * 32, size), dtype=torch.float32, device="cuda") for _ in range(2)]
+          rq, xq = parallel.TorchQueue(), parallel.TorchQueue()
+          state = {"k": 0}
+          pipe = parallel.ExchangePipeline(
+              lambda b: sets[state["k"]].render(shard[b].data_ptr(), fs0.out_bytes, abi.FUSED_CLEAR, rq.handle),
+              lambda b: fs0.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), abi.EXCHANGE_PLANES, xq.handle),
+              rq, xq)
+          ok, snaps = True, []
+          for k in range(steps):   # a different set of frames every step: a torn or stale buffer cannot go unnoticed
+              state["k"] = k
+              b = pipe.step()
+              with torch.cuda.stream(xq.stream):
+                  snaps.append(full[b].clone())
+          pipe.drain()
+          torch.cuda.synchronize()
+          for k in range(steps):
+              got = snaps[k].cpu().numpy()[:, :, :size]
+              for i in range(nf):
+                  ref = np.stack(oracle.draw(scenes.config2(3 * k + i, size=size))[1])
+                  ok = ok and np.array_equal(got[i].view(np.uint32), ref.view(np.uint32))
+          q.put((rank, ok))
+          comm.close()
+      except BaseException as e:  # noqa: BLE001  (the parent must not wait 300 s for a worker that died)
+        q.put((rank, f"worker failed: {e!r}"))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -167,4 +255,4 @@ def test_two_ranks_overlapped_exchange_equals_oracle():
     res = [q.get(timeout=300) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
-    assert all(ok for _, ok in res), res
+    assert all(ok is True for _, ok in res), res

@@ -365,6 +365,27 @@ def test_two_lanes_at_batch_size_take_turns_and_match_the_oracle(orc):
     ctx.close()
 
 
+def test_lane_renderer_default_flags_are_the_fused_clear(orc):
+    """LaneRenderer.render(ptr) with no flags must mean what FrameSet.render(ptr, bytes) means: the buffer counts as just
+    cleared.  (Round 2's default was SRZ_UNIFIED = accumulate with 8-wide semantics: a torch.empty buffer then fed garbage
+    depths into the draw.)"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    frames = [scenes.config2(i, size=256) for i in range(16)]
+    lr = parallel.LaneRenderer(ctx, frames, 2)
+    out = torch.full(lr.out_shape, float("nan"), dtype=torch.float32, device="cuda")  # NaN depths: poison for an accumulating draw
+    lr.render(out.data_ptr())
+    lr.synchronize()
+    got = out.cpu().numpy()
+    for i in (0, 7, 8, 15):
+        ref = orc.draw(frames[i])[1]
+        for p in range(4):
+            assert np.array_equal(bits(got[i, p]), bits(ref[p])), (i, p)
+    lr.close()
+    ctx.close()
+
+
 def test_large_set_rendered_as_sub_batches_matches_the_oracle(orc, monkeypatch):
     """a large set is rendered as sub-batches of whole frames one after the other (shared counters, pool and work lists; the
     size is 192 frames' worth of 1024^2 in tiles — forced to 104 frames here, small frames being cheap to check): 328 frames,
