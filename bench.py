@@ -30,11 +30,16 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "software-rasterizer_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_SIMD, SCLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max shader clock (same guide)
 HBM_MEASURED_COPY_GBS = 6290.0
 XGMI_LINK_GBS = 153.0  # per link, per direction (7 links per GPU)
 # the other GPU configs of BASELINE.json, whole frames on one GPU: (workload, frames per step, steps)
 EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 128, 20), ("spot_x8_overdraw_4096", 64, 20),
-               ("readme_spot_crate_1024", 256, 20)]  # (+ the scene of the reference's one published raster figure)
+               ("readme_spot_crate_1024", 256, 20),  # (+ the scene of the reference's one published raster figure)
+               # configs[1] away from the benchmark's own shading parameters: 3 lights, p = 32 (FAST builds of k_shade for other
+               # counts / exponents), p = 7.5 (the generic build), the BUMP shader
+               ("spot_texture_1024_3lights", 256, 10), ("spot_texture_1024_p32", 256, 10), ("spot_texture_1024_p7.5", 256, 10),
+               ("spot_bump_1024", 256, 10)]
 
 
 def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
@@ -314,11 +319,43 @@ def time_multi_gpu(case, comm, dist, steps, warmup, fence, exchange="planes", no
     return dt, kt, [], multi
 
 
+_PMC = None
+
+
+def pmc_counters(workload, frames_per_step, scope):
+    """HBM bytes and VALU wave-instructions per step of this workload from profiles/pmc_counters.json — the rocprofv3 --pmc passes
+    of the same bench.py command with --lanes 1 (profiles/collect.sh; the counters are per dispatch, i.e. per step of a
+    one-stream run: the bytes and instructions of a step do not depend on how its launches are spread over streams).  NOT
+    measured in this run: a profile of another code version describes that version."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(REPO, "profiles", "pmc_counters.json")))
+        except Exception:  # noqa: BLE001
+            _PMC = {}
+    t = _PMC.get(workload)
+    if not t or t.get("frames_per_step") != frames_per_step or scope != "raster":
+        return None
+    return t
+
+
 def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
     fs = case.fs
     fps = case.n_frames * steps / dt
     pipeline_s = kt["total_ms"] * 1e-3
     achieved = case.algo_bytes / pipeline_s / 1e9 if pipeline_s > 0 else 0.0
+    pm = pmc_counters(case.name, case.n_frames, case.scope) if case.world == 1 else None
+    # VALU issue beside the HBM fraction (a kernel can sit far below the HBM roofline because it is bound by instruction issue):
+    # wave-instructions per step / what the 1024 SIMDs issue in the step's device time at one wave64 VALU instruction per 4
+    # cycles — one wave's own issue rate; a SIMD-32 that interleaves two or more waves retires one every 2 cycles, so 0.5 by
+    # this measure is a saturated pipe only for code without ILP between waves, and 1.0 would be every SIMD issuing back to back
+    valu = None
+    if pm and pipeline_s > 0:
+        valu = {"valu_wave_insts_per_step": pm["valu_wave_insts_per_step"],
+                "valu_frac": pm["valu_wave_insts_per_step"] / (N_SIMD * SCLK_HZ * pipeline_s / 4.0),
+                "valu_per_64_visible_px": pm["valu_wave_insts_per_step"] / max(1.0, vis_total / 64.0),
+                "definition": "SQ_INSTS_VALU per step / (1024 SIMDs x 2.4 GHz x launch_ms / 4)",
+                "source": f"profiles/{pm['from']} (rocprofv3 --pmc pass of this workload, --lanes 1; not measured in this run)"}
     return {
         "workload": case.name, "scope": case.scope, "lanes": kt.get("lanes", 1), "width": fs.width, "height": fs.height,
         "frames_per_step": case.n_frames, "triangles_per_frame": case.tris_per_frame, "steps": steps,
@@ -327,7 +364,10 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
         "us_per_frame_median": (pct(per_step, 0.5) * 1e3 / case.n_frames) if per_step else None,
         "mfragments_per_sec": frag_total / fs.n_frames * fps / 1e6,
         "fragments_per_frame": frag_total / fs.n_frames, "visible_pixels_per_frame": vis_total / fs.n_frames,
+        "valu": valu,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pm["hbm_bytes_per_step"] if pm else None,
+                     "traffic_over_algorithmic": pm["hbm_bytes_per_step"] / case.algo_bytes if pm else None,
                      "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
                      "lanes": kt.get("lanes", 1), "lane_launch_ms": kt.get("lane_launch_ms"),
                      "one_stream": {"ms_per_step": kt.get("one_stream_ms_per_step"), "launch_ms": kt.get("split_total_ms"),
@@ -410,15 +450,8 @@ def main():
     res = None
     if rank == 0:
         rec = case_record(case, args.steps, dt, kt, per_step, frag_total, vis_total)
-        traffic, traffic_src = None, None
-        tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and world == 1:
-            try:
-                t = json.load(open(tfile)).get(args.workload, {})
-                if t.get("frames_per_launch") == case.n_frames and args.scope == "raster":
-                    traffic, traffic_src = t.get("hbm_bytes_per_launch"), f"profiles/{t.get('from')}"
-            except Exception:  # noqa: BLE001
-                traffic = None
+        pm = pmc_counters(args.workload, case.n_frames, args.scope) if world == 1 else None
+        traffic, traffic_src = (pm["hbm_bytes_per_step"], f"profiles/{pm['from']}") if pm else (None, None)
         roof = rec["roofline"]
         roof.update({"traffic": traffic,
                      "traffic_source": (f"{traffic_src}: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 --pmc passes of this command with --lanes 1 "
@@ -438,13 +471,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": fs.width, "height": fs.height,
                        "frames_per_step": case.n_frames, "frames_per_step_per_gpu": args.frames,
-                       "triangles_per_frame": case.tris_per_frame, "lights": 2, "scope": args.scope,
+                       "triangles_per_frame": case.tris_per_frame, "lights": len(case.frames[0].lights), "scope": args.scope,
                        "sharding": "whole frames on 1 GPU" if world == 1 else
                        f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {args.exchange} + de-interleave (timed)"},
             "mfragments_per_sec": rec["mfragments_per_sec"], "fragments_per_frame": rec["fragments_per_frame"],
             "visible_pixels_per_frame": rec["visible_pixels_per_frame"],
             "ms_per_step_p10_median_p90": rec["ms_per_step_p10_median_p90"], "us_per_frame_median": rec["us_per_frame_median"],
-            "roofline": roof,
+            "roofline": roof, "valu": rec["valu"],
             "reference_published": {"fps": 58.6, "note": "README.md:619-629, i7-12800HX/MSVC, spot+crate 5-mesh scene, "
                                     "draw() incl. vertex stage — different workload/hardware, not reproducible here"},
         }

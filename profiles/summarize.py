@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_<tag>/ (written by profiles/collect.sh on the GPU box) into the committed summaries:
-profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, and profiles/pmc_traffic.json (read by bench.py).
 
-HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 WRITE_SIZE
-is byte-exact for 16-byte-per-lane streaming stores (our framebuffer stores), FETCH_SIZE reports 1/2 of the bytes of wide
-coalesced reads, so the read side is given both raw and doubled; other widths are uncalibrated (stated in the json)."""
+  profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats of the headline command, one stream (--lanes 1)
+  profiles/<tag>_lanes_kernel_stats.csv    the same for the default two-lane command
+  profiles/<tag>_<workload>_kernel_stats.csv   for every configs[] workload
+  profiles/<tag>_pmc.json                  per workload and kernel: average duration, FETCH_SIZE / WRITE_SIZE bytes, SQ counters
+  profiles/pmc_counters.json               per workload: HBM bytes and VALU instructions per step (read by bench.py → roofline.traffic
+                                           and valu_frac of the headline and of every configs[] entry)
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 WRITE_SIZE is
+byte-exact for 16-byte-per-lane streaming stores (the framebuffer stores), FETCH_SIZE reports 1/2 of the bytes of wide coalesced
+reads, so the read side is doubled; other widths are uncalibrated (stated in the json)."""
 import collections
 import csv
 import glob
@@ -13,18 +19,17 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(os.path.dirname(here), "gpurun_out", f"prof_{tag}")
-# (matched in this order: "k_raster_slow" before "k_raster"; k_shade_fast / k_shade_generic = the two builds of k_shade)
-KERNELS = ("k_setup", "k_bin", "k_raster_slow", "k_raster", "k_clear", "k_shade_fast", "k_shade_generic")
+KERNELS = ("k_setup", "k_chunks", "k_vertex", "k_bin", "k_raster_slow", "k_raster", "k_clear", "k_shade_fast", "k_shade_generic")
 
 
 def kernel_of(name):
     if "<true" in name:  # counting variants (run once, outside the timed region)
         return None
     if "k_shade" in name:
-        return "k_shade_fast" if "k_shade<false, true>" in name else "k_shade_generic"
+        return "k_shade_generic" if "k_shade<false, 0>" in name else "k_shade_fast"
     for k in KERNELS:
         if k in name:
             return k
@@ -37,69 +42,71 @@ def one(pattern):
     return max(g, key=os.path.getmtime)  # (gpurun merges runs into the same scratch directory: take the latest)
 
 
-shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_stats.csv"))
-try:  # the default command (two lanes on two streams: the kernels of the lanes overlap; half a batch per launch)
-    shutil.copy(one("trace_lanes/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_lanes_kernel_stats.csv"))
-except AssertionError:
-    pass
-stats = {r["Name"]: r for r in csv.DictReader(open(one("trace/**/*kernel_stats.csv")))}
-per_kernel_us = {}
-for name, r in stats.items():
-    k = kernel_of(name)
-    if k:
-        per_kernel_us[k] = float(r["AverageNs"]) / 1e3
+def kernel_us(path):
+    us = {}
+    for r in csv.DictReader(open(path)):
+        k = kernel_of(r["Name"])
+        if k:
+            us[k] = us.get(k, 0.0) + float(r["AverageNs"]) / 1e3
+    return us
 
 
 def pmc(dirname):
+    """per kernel: counter → average per dispatch (the steady-state dispatches: the first quarter of them is warm-up)"""
     rows = list(csv.DictReader(open(one(f"{dirname}/**/*counter_collection.csv"))))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k = kernel_of(r["Kernel_Name"])
         if k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+    return {k: {c: sum(v[len(v) // 4:]) / max(1, len(v) - len(v) // 4) for c, v in d.items()} for k, d in agg.items()}
 
 
-fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
-traced = json.loads(open(os.path.join(src, "bench_traced.json")).read().strip().splitlines()[-1])  # the --lanes 1 run under the tracer
-out = {"tag": tag, "bench_line": bench, "avg_kernel_us": per_kernel_us, "pipeline_us_sum": sum(v for k, v in per_kernel_us.items() if k != "k_clear"),
-       "note": "k_clear runs on a second stream beside k_raster/k_shade: its time overlaps theirs and is not in pipeline_us_sum",
-       "pmc_avg_per_launch": {}, "units": "FETCH_SIZE/WRITE_SIZE in KiB (rocprofv3); bytes below = KiB*1024"}
-tot_w = tot_f = 0.0
-for k in KERNELS:
-    f = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024
-    w = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
-    tot_f += f
-    tot_w += w
-    out["pmc_avg_per_launch"][k] = {"fetch_bytes_raw": f, "write_bytes": w, **sq.get(k, {})}
-algo = bench["roofline"]["algorithmic_bytes_per_launch"]
-out["hbm_bytes_per_launch"] = {"write": tot_w, "fetch_raw": tot_f, "fetch_x2_gfx950_correction": 2 * tot_f,
-                               "total_corrected": tot_w + 2 * tot_f, "algorithmic": algo,
-                               "ratio_traffic_over_algorithmic": (tot_w + 2 * tot_f) / algo}
-json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
-tfile = os.path.join(here, "pmc_traffic.json")
-t = json.load(open(tfile)) if os.path.exists(tfile) else {}
-t[bench["config"]["workload"]] = {"hbm_bytes_per_launch": tot_w + 2 * tot_f, "from": f"{tag}_pmc.json",
-                                  "frames_per_launch": bench["config"]["frames_per_step"]}
-json.dump(t, open(tfile, "w"), indent=1)
-print(json.dumps(out["hbm_bytes_per_launch"], indent=1))
-print(per_kernel_us, "one-stream events total ms:", bench["roofline"]["one_stream"]["launch_ms"], "| traced --lanes 1 run:", traced["roofline"]["launch_ms"])
-
-# ---- the other BASELINE configs (tests/perf_probe.py under the same two profiler modes) ---------------------------------
-others = {}
-for n, label in ((3, "spot_bunny_phong_1080p x64"), (4, "spot_x16_texture_2048 x32"), (5, "spot_x8_overdraw_4096 x16")):
+head = bench["config"]["workload"]
+out = {"tag": tag, "bench_line": bench, "units": "FETCH_SIZE / WRITE_SIZE in KiB (rocprofv3); bytes below = KiB * 1024; "
+       "durations: µs per dispatch = per step (one frameset on one stream: bench.py --lanes 1); k_clear runs on a second stream beside "
+       "k_raster / k_shade and is not part of pipeline_us_sum", "workloads": {}}
+counters_file = os.path.join(here, "pmc_counters.json")
+counters = json.load(open(counters_file)) if os.path.exists(counters_file) else {}
+try:
+    shutil.copy(one("trace_lanes/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_lanes_kernel_stats.csv"))
+except AssertionError:
+    pass
+for jf in sorted(glob.glob(os.path.join(src, "*.traced.json"))):
+    w = os.path.basename(jf)[:-len(".traced.json")]
     try:
-        shutil.copy(one(f"trace_c{n}/**/*kernel_stats.csv"), os.path.join(here, f"{tag}_c{n}_kernel_stats.csv"))
-        us = {}
-        for r in csv.DictReader(open(one(f"trace_c{n}/**/*kernel_stats.csv"))):
-            k = kernel_of(r["Name"])
-            if k:
-                us[k] = float(r["AverageNs"]) / 1e3
-        others[f"config{n}"] = {"workload": label, "avg_kernel_us": us, "sq_avg_per_launch": pmc(f"pmc_sq_c{n}")}
-    except AssertionError:
-        pass
-if others:
-    json.dump(others, open(os.path.join(here, f"{tag}_configs_pmc.json"), "w"), indent=1)
-    for k, v in others.items():
-        print(k, {a: round(b) for a, b in v["avg_kernel_us"].items()})
+        line = json.loads(open(jf).read().strip().splitlines()[-1])
+        stats = one(f"{w}/trace/**/*kernel_stats.csv")
+        shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv" if w == head else f"{tag}_{w}_kernel_stats.csv"))
+        us = kernel_us(stats)
+        fetch, write, sq = pmc(f"{w}/pmc_fetch"), pmc(f"{w}/pmc_write"), pmc(f"{w}/pmc_sq")
+    except (AssertionError, ValueError, IndexError) as e:
+        print("skipped", w, e)
+        continue
+    per_kernel, tot_f, tot_w, tot_valu = {}, 0.0, 0.0, 0.0
+    for k in KERNELS:
+        if k not in us and k not in sq:
+            continue
+        f = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024
+        wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+        tot_f, tot_w, tot_valu = tot_f + f, tot_w + wr, tot_valu + sq.get(k, {}).get("SQ_INSTS_VALU", 0.0)
+        per_kernel[k] = {"avg_us": us.get(k), "fetch_bytes_raw": f, "write_bytes": wr, **sq.get(k, {})}
+    algo = line["roofline"]["algorithmic_bytes_per_launch"]
+    frames = line["config"]["frames_per_step"]
+    out["workloads"][w] = {"frames_per_step": frames, "kernels": per_kernel,
+                           "pipeline_us_sum": sum(v for k, v in us.items() if k != "k_clear"),
+                           "traced_run": {"ms_per_step": line["ms_per_step"], "launch_ms": line["roofline"]["launch_ms"]},
+                           "hbm_bytes_per_step": {"write": tot_w, "fetch_raw": tot_f, "fetch_x2_gfx950_correction": 2 * tot_f,
+                                                  "total_corrected": tot_w + 2 * tot_f, "algorithmic": algo,
+                                                  "ratio_traffic_over_algorithmic": (tot_w + 2 * tot_f) / algo},
+                           "valu_wave_insts_per_step": tot_valu,
+                           "valu_per_64_visible_px": tot_valu / max(1.0, line["visible_pixels_per_frame"] * frames / 64.0)}
+    counters[w] = {"frames_per_step": frames, "hbm_bytes_per_step": tot_w + 2 * tot_f, "valu_wave_insts_per_step": tot_valu,
+                   "from": f"{tag}_pmc.json"}
+    print(f"{w:28s} pipeline {out['workloads'][w]['pipeline_us_sum']:8.1f} us  traffic/algorithmic {(tot_w + 2 * tot_f) / algo:.3f}  "
+          f"VALU {tot_valu / 1e6:7.1f} M  per 64 visible px {out['workloads'][w]['valu_per_64_visible_px']:.0f}  "
+          + " ".join(f"{k[2:]}={v:.0f}" for k, v in us.items()))
+json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
+json.dump(counters, open(counters_file, "w"), indent=1)
+shutil.copy(os.path.join(src, "bench_plain.json"), os.path.join(here, f"{tag}_bench.json"))

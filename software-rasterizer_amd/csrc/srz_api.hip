@@ -107,7 +107,8 @@ struct srz_frameset {
   uint2 *d_tile_info = nullptr;
   uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr;
   uint32_t *d_redo_list = nullptr; // (its counter is d_slow_count[1])
-  bool any_fast = false, any_generic = true; // which builds of k_shade the frames need (classify_frames)
+  uint32_t fast_mask = 0;   // bit NL (+ 8 with BUMP / DISPLACEMENT batches): some frame is shaded by that FAST build of k_shade (classify_frames)
+  bool any_generic = true;  // some frame needs the generic build
   uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr;
   uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
   uint2 *d_band_ent = nullptr;     // and entries [group][ENT_PER_GROUP]
@@ -165,18 +166,24 @@ void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &
   local_rows = world == 1 ? (uint32_t)height : per_rank * BAND;
 }
 
-// Which frames can be shaded by k_shade's FAST build: exactly 2 lights, p == 150 (Shader::p as the reference ships it,
-// src/Shader.cpp:10) and only NORMAL / TEXTURE / PHONG batches.  Sets FD_FAST_SHADE in the host copies of the descriptors.
+// Which frames the FAST builds of k_shade can shade: 1..4 lights and an integer exponent 0 <= p <= 256 (Shader::p is 150 as the
+// reference ships it, src/Shader.cpp:10; any light count and exponent are legal there, src/Shader.cpp:192-386) — every shader
+// type qualifies.  Sets FD_FAST_SHADE + the light count in the host copies of the descriptors.
 void classify_frames(srz_frameset *fs) {
-  fs->any_fast = false, fs->any_generic = false;
+  fs->fast_mask = 0, fs->any_generic = false;
   for (FrameDesc &d : fs->h_frames) {
-    bool fast = d.n_lights == 2u && d.p == 150.0f;
-    for (uint32_t b = 0; fast && b < d.n_batches; ++b) {
+    const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && d.p >= 0.0f && d.p <= 256.0f && d.p == std::trunc(d.p);
+    bool bumpy = false;
+    for (uint32_t b = 0; b < d.n_batches; ++b) {
       const int sh = fs->h_batches[d.batch_off + b].shader;
-      fast = sh == SRZ_SHADER_NORMAL || sh == SRZ_SHADER_TEXTURE || sh == SRZ_SHADER_PHONG;
+      bumpy = bumpy || sh == SRZ_SHADER_BUMP || sh == SRZ_SHADER_DISPLACEMENT;
     }
-    d.flags = (d.flags & ~FD_FAST_SHADE) | (fast ? FD_FAST_SHADE : 0u);
-    (fast ? fs->any_fast : fs->any_generic) = true;
+    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | (7u << FD_NL_SHIFT))) |
+              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u)) : 0u);
+    if (fast)
+      fs->fast_mask |= 1u << (d.n_lights + (bumpy ? 8u : 0u));
+    else
+      fs->any_generic = true;
   }
 }
 
@@ -478,7 +485,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       ctx->raster_last_stream = s, ctx->raster_valid = true;
     }
     if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
-    launch_shade(v, tiles, stats, fs->any_fast, fs->any_generic, s);
+    launch_shade(v, tiles, stats, fs->fast_mask, fs->any_generic, s);
     if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
     else if (!raster_four_waves(v))
       if (int rc = copy_demand(s)) return rc;

@@ -21,9 +21,11 @@ constexpr uint32_t NO_TRI = 0xffffffffu;
 // per-frame atomic counters sit 128 bytes apart: atomics on the words of ONE cache line serialise (~10 ns each across the
 // device) as if they were one address — with 16 frames of 4096^2 that was the whole of k_raster's time
 constexpr uint32_t CNT_STRIDE = 32;
-// FrameDesc::flags, internal (set by the host): 2 lights, p == 150, every batch NORMAL / TEXTURE / PHONG → k_shade's FAST build
-constexpr uint32_t FD_FAST_SHADE = 0x100u;
-constexpr uint32_t N_WORK_LISTS = 16;
+// FrameDesc::flags, internal (set by the host): 1..4 lights and an integer exponent 0..256 → the FAST build of k_shade for that count
+constexpr uint32_t FD_FAST_SHADE = 0x100u, FD_NL_SHIFT = 9; // (+ the light count 1..4 in bits 9..11)
+constexpr uint32_t FD_BUMPY = 0x1000u;                   // some batch of the frame is BUMP / DISPLACEMENT (FAST builds with those variants)
+constexpr uint32_t SHADE_KIND_GENERIC = 8;               // k_shade builds: kinds 0..3 = FAST for 1..4 lights, 4..7 = the same + BUMPY, 8 = generic
+constexpr uint32_t N_WORK_LISTS = 8 * (SHADE_KIND_GENERIC + 1);
 constexpr uint32_t UNLISTED = 0xffffffffu; // tile_off of a tile whose list did not fit the record pool
 // Binning is O(triangles): k_setup / k_chunks sort every GROUP of GROUP_TRIS (512) consecutive triangles by the 32-row bands their
 // bounding boxes reach (LDS count / scan / fill, no global atomics) into the group's own region of ENT_PER_GROUP 8-byte
@@ -140,7 +142,7 @@ struct RenderArgs {
   uint32_t *redo_count;
   uint32_t vis16;                // the owner-id plane holds 16-bit ids (every frame of the set has < 32768 triangles)
   uint32_t *vis;                 // owner ids [frame][local_rows][width], written only for tiles that have an owner
-  // k_shade's work: N_WORK_LISTS lists [FAST / generic build][frame % 8] of the tiles that have an owner, as
+  // k_shade's work: N_WORK_LISTS lists [build: FAST for 1..4 lights, generic][frame % 8] of the tiles that have an owner, as
   // frame * tiles_per_frame + (lb*tiles_x + tx), in arrival order; work_cap entries each
   uint32_t *worklist;
   uint32_t *work_count;          // [list * CNT_STRIDE]: word 0 = entries (zeroed by k_setup, bumped by k_raster), word 1 = k_shade's cursor
@@ -163,7 +165,7 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
 void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);
 bool raster_four_waves(const RenderArgs &a); // the latency build of k_raster serves this job (it also reports the pool's demand)
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
-void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s);
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s);
 void launch_deinterleave(const void *gathered, void *full, uint32_t world, uint32_t n_fp, uint32_t bands_per_rank, uint32_t row_bytes,

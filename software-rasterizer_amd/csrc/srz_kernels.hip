@@ -212,11 +212,29 @@ __device__ __forceinline__ float pow150_cr(float x) {
   r = r * b128;
   return (float)r;
 }
+// x^n for an integer exponent 0..256 that is the same for the whole wave (a per-frame constant): pow_cr's square-and-multiply
+// chain as a SCALAR loop — the very same binary64 multiplications in the same order, no per-lane selects
+__device__ __forceinline__ float pow_int_cr(float x, float p) {
+  unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p);
+  double b = (double)x, r = 1.0;
+  while (n) {
+    if (n & 1u) r = r * b;
+    b = b * b;
+    n >>= 1;
+  }
+  return (float)r;
+}
 // Compile-time knowledge a shading variant may have (k_shade picks the variant per 64-pixel chunk, wave-uniformly):
 //   SH   >= 0: every pixel of the chunk uses shader type SH; -1: per-pixel type (sd.shader)
-//   L2P150   : the frame has exactly 2 lights and p == 150 (the reference's README scene and Shader::p default):
-//              the light loop is unrolled, the light constants sit in SGPRs and the exponent is the fixed chain
-template <bool L2P150> __device__ __forceinline__ float pow_frame(float x, float p) { return L2P150 ? pow150_cr(x) : pow_cr(x, p); }
+//   NL   >  0: the frame has exactly NL lights (1..4) and an integer exponent 0 <= p <= 256 (decided on the host): the light loop
+//              is unrolled, the light constants sit in SGPRs, and the exponent is the fixed chain for p = 150 (Shader::p as the
+//              reference ships it, src/Shader.cpp:10) or the scalar square-and-multiply loop;  0: run-time count, any exponent
+template <int NL> __device__ __forceinline__ float pow_frame(float x, float p) {
+  if constexpr (NL > 0)
+    return p == 150.0f ? pow150_cr(x) : pow_int_cr(x, p); // (wave-uniform branch: p is a per-frame scalar)
+  else
+    return pow_cr(x, p);
+}
 
 __device__ __forceinline__ int32_t cvt_rne_i32(float f) {
   if (!(f >= -2147483648.0f && f < 2147483648.0f)) return INT32_MIN;
@@ -714,7 +732,7 @@ struct ShadeDesc { // what a batch's Shader object holds: type + texture (Shader
 };
 
 // BlinnPhong<__m256> for one light (include/shader/Shader.hpp:104-229)
-template <class M, bool L2P150>
+template <class M, int NL>
 __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz, const FrameK &K, float kdr, float kdg, float kdb,
                                               const SRZ_CAS srz_light *L, float px, float py, float pz, float &o0, float &o1,
                                               float &o2) {
@@ -727,7 +745,7 @@ __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz
   float nlx = lx, nly = ly, nlz = lz;
   v_normalized(m, nlx, nly, nlz);
   float cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
-  float cosT = pow_frame<L2P150>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+  float cosT = pow_frame<NL>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
   o0 = kdr * fmaf_(K.ka[0], I0, fmaf_(d0 * kdr, cosA, (d0 * K.ks[0]) * cosT));
   o1 = kdg * fmaf_(K.ka[1], I1, fmaf_(d1 * kdg, cosA, (d1 * K.ks[1]) * cosT));
   o2 = kdb * fmaf_(K.ka[2], I2, fmaf_(d2 * kdb, cosA, (d2 * K.ks[2]) * cosT));
@@ -738,7 +756,7 @@ __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz
 struct LightTerms {
   float d0, d1, d2, cosA, cosT;
 };
-template <class M, bool L2P150>
+template <class M, int NL>
 __device__ __forceinline__ void v_blinn_phong_terms(M &m, float nx, float ny, float nz, const FrameK &K, const SRZ_CAS srz_light *L,
                                                     float px, float py, float pz, LightTerms &t) {
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
@@ -750,7 +768,7 @@ __device__ __forceinline__ void v_blinn_phong_terms(M &m, float nx, float ny, fl
   float nlx = lx, nly = ly, nlz = lz;
   v_normalized(m, nlx, nly, nlz);
   t.cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
-  t.cosT = pow_frame<L2P150>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+  t.cosT = pow_frame<NL>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
 }
 __device__ __forceinline__ void v_blinn_phong_combine(const FrameK &K, const SRZ_CAS srz_light *L, const LightTerms &t, float kdr,
                                                       float kdg, float kdb, float &o0, float &o1, float &o2) {
@@ -761,11 +779,11 @@ __device__ __forceinline__ void v_blinn_phong_combine(const FrameK &K, const SRZ
 }
 
 // Shader::applyFragmentShader SIMD overload + simd_*_impl (src/Shader.cpp:128-386); colour out in [0,255]
-template <class M, int SH, bool L2P150>
+template <class M, int SH, int NL>
 __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
   const int shader = SH >= 0 ? SH : sd.shader;
-  const uint32_t n_lights = L2P150 ? 2u : K.n_lights;
+  const uint32_t n_lights = NL > 0 ? (uint32_t)NL : K.n_lights;
   float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f;
   if (shader == SRZ_SHADER_NORMAL) {
     c0 = (nx + 1.0f) * 0.5f, c1 = (ny + 1.0f) * 0.5f, c2 = (nz + 1.0f) * 0.5f;
@@ -788,24 +806,25 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
       }
     };
     c0 = c1 = c2 = 0.0f;
-    if constexpr (L2P150) { // both lights' colour-independent terms first, the texel only after them
-      LightTerms t0, t1;
-      v_blinn_phong_terms<M, true>(m, nx, ny, nz, K, K.lights, px, py, pz, t0);
-      v_blinn_phong_terms<M, true>(m, nx, ny, nz, K, K.lights + 1, px, py, pz, t1);
-      asm volatile("" : "+v"(t0.cosT), "+v"(t1.cosT), "+v"(texel)); // (keeps the decode below the terms)
+    if constexpr (NL > 0) { // every light's colour-independent terms first, the texel only after them
+      LightTerms t[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) v_blinn_phong_terms<M, NL>(m, nx, ny, nz, K, K.lights + l, px, py, pz, t[l]);
+      asm volatile("" : "+v"(t[0].cosT), "+v"(t[NL - 1].cosT), "+v"(texel)); // (keeps the decode below the terms)
       decode();
-      float o0, o1, o2;
-      v_blinn_phong_combine(K, K.lights, t0, kd0, kd1, kd2, o0, o1, o2);
-      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
-      v_blinn_phong_combine(K, K.lights + 1, t1, kd0, kd1, kd2, o0, o1, o2);
-      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { // (summed in the lights' order, like the loop below)
+        float o0, o1, o2;
+        v_blinn_phong_combine(K, K.lights + l, t[l], kd0, kd1, kd2, o0, o1, o2);
+        c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+      }
     } else {
       decode();
-    }
-    for (uint32_t l = 0; l < (L2P150 ? 0u : n_lights); ++l) { // (2 iterations known at compile time when L2P150: unrolled by the optimizer)
-      float o0, o1, o2;
-      v_blinn_phong<M, L2P150>(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
-      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+      for (uint32_t l = 0; l < n_lights; ++l) {
+        float o0, o1, o2;
+        v_blinn_phong<M, NL>(m, nx, ny, nz, K, kd0, kd1, kd2, K.lights + l, px, py, pz, o0, o1, o2);
+        c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+      }
     }
   }
   // DISPLACEMENT / BUMP: the reference's SIMD versions are empty stubs (src/Shader.cpp:388-444) → (1,1,1) → 255
@@ -830,7 +849,7 @@ __device__ __forceinline__ void s_texel(M &m, const ShadeDesc &sd, float u, floa
 }
 
 // Shader::BlinnPhong scalar (src/Shader.cpp:510-543); the two std::pow(x,2) and the sqrt are binary64 there
-template <class M, bool L2P150>
+template <class M, int NL>
 __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
                                               float kd0, float kd1, float kd2, const SRZ_CAS srz_light *L, float &o0, float &o1,
                                               float &o2) {
@@ -848,13 +867,13 @@ __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, f
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
   normalize3(m, hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
-  float pw = pow_frame<L2P150>(cosAlpha, K.p);
+  float pw = pow_frame<NL>(cosAlpha, K.p);
   o0 = ((K.ka[0] * I0 + (cosTheta * kd0) * d0) + (pw * K.ks[0]) * d0) * kd0;
   o1 = ((K.ka[1] * I1 + (cosTheta * kd1) * d1) + (pw * K.ks[1]) * d1) * kd1;
   o2 = ((K.ka[2] * I2 + (cosTheta * kd2) * d2) + (pw * K.ks[2]) * d2) * kd2;
 }
 // the same light in two steps (see v_blinn_phong_terms): cosA = cosTheta, cosT = pow(cosAlpha, p)
-template <class M, bool L2P150>
+template <class M, int NL>
 __device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float px, float py, float pz, float nx, float ny, float nz,
                                                     const SRZ_CAS srz_light *L, LightTerms &t) {
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
@@ -870,7 +889,7 @@ __device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
   normalize3(m, hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
-  t.cosT = pow_frame<L2P150>(cosAlpha, K.p);
+  t.cosT = pow_frame<NL>(cosAlpha, K.p);
 }
 __device__ __forceinline__ void s_blinn_phong_combine(const FrameK &K, const SRZ_CAS srz_light *L, const LightTerms &t, float kd0,
                                                       float kd1, float kd2, float &o0, float &o1, float &o2) {
@@ -912,11 +931,11 @@ __device__ __forceinline__ void s_bump_common(M &m, const ShadeDesc &sd, float n
 }
 
 // scalar applyFragmentShader + standard_*_impl + Tools::normalizedToRGB (src/Shader.cpp:547-640, src/Tools.cpp:94-104)
-template <class M, int SH, bool L2P150>
+template <class M, int SH, int NL>
 __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
   const int shader = SH >= 0 ? SH : sd.shader;
-  const uint32_t n_lights = L2P150 ? 2u : K.n_lights;
+  const uint32_t n_lights = NL > 0 ? (uint32_t)NL : K.n_lights;
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   if (shader == SRZ_SHADER_NORMAL) {
     normalize3(m, nx, ny, nz);
@@ -924,24 +943,25 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
   } else if (shader >= SRZ_SHADER_TEXTURE && shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
     float sx = px, sy = py, sz = pz, snx = nx, sny = ny, snz = nz;
-    if constexpr (L2P150 && (SH == SRZ_SHADER_TEXTURE || SH == SRZ_SHADER_PHONG)) {
-      // FAST build: texel load issued first, both lights' colour-independent terms, then the texel and the combination
+    if constexpr (NL > 0 && (SH == SRZ_SHADER_TEXTURE || SH == SRZ_SHADER_PHONG)) {
+      // FAST build: texel load issued first, every light's colour-independent terms, then the texel and the combination
       bool inside = true;
       uint32_t texel = 0u;
       if (SH == SRZ_SHADER_TEXTURE) texel = s_texel_issue(sd, u, v, inside);
-      LightTerms t0, t1;
-      s_blinn_phong_terms<M, true>(m, K, sx, sy, sz, snx, sny, snz, K.lights, t0);
-      s_blinn_phong_terms<M, true>(m, K, sx, sy, sz, snx, sny, snz, K.lights + 1, t1);
-      asm volatile("" : "+v"(t0.cosT), "+v"(t1.cosT), "+v"(texel));
+      LightTerms t[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) s_blinn_phong_terms<M, NL>(m, K, sx, sy, sz, snx, sny, snz, K.lights + l, t[l]);
+      asm volatile("" : "+v"(t[0].cosT), "+v"(t[NL - 1].cosT), "+v"(texel));
       if (SH == SRZ_SHADER_TEXTURE) {
         kd0 = m.div255((float)(texel & 0xffu)), kd1 = m.div255((float)((texel >> 8) & 0xffu)), kd2 = m.div255((float)((texel >> 16) & 0xffu));
         if (!inside) kd0 = kd1 = kd2 = 0.0f;
       }
-      float o0, o1, o2;
-      s_blinn_phong_combine(K, K.lights, t0, kd0, kd1, kd2, o0, o1, o2);
-      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
-      s_blinn_phong_combine(K, K.lights + 1, t1, kd0, kd1, kd2, o0, o1, o2);
-      c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        float o0, o1, o2;
+        s_blinn_phong_combine(K, K.lights + l, t[l], kd0, kd1, kd2, o0, o1, o2);
+        c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
+      }
     } else {
     if (shader != SRZ_SHADER_PHONG) s_texel(m, sd, u, v, kd0, kd1, kd2);
     if (shader == SRZ_SHADER_BUMP) {
@@ -954,7 +974,7 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
     }
     for (uint32_t l = 0; l < n_lights; ++l) {
       float o0, o1, o2;
-      s_blinn_phong<M, L2P150>(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
+      s_blinn_phong<M, NL>(m, K, sx, sy, sz, snx, sny, snz, kd0, kd1, kd2, K.lights + l, o0, o1, o2);
       c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
     }
     }
@@ -966,12 +986,14 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
   r2 = (q2 == q2) ? (float)(uint32_t)q2 : 0.0f;
 }
 
-// A tile that has an owner goes to one of 16 work lists for k_shade: [build that shades the frame: FAST / generic][frame % 8]
-// (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so every list
-// comes out (roughly) frame by frame.
+// A tile that has an owner goes to one of 72 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
+// the same for frames with BUMP / DISPLACEMENT batches, generic][frame % 8] (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so
+// every list comes out (roughly) frame by frame.
 __device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
-  const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u) ? 0u : 1u;
+  const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
+                            ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u)
+                            : SHADE_KIND_GENERIC;
   const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
   a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = entry;
 }
@@ -1035,7 +1057,7 @@ template <class M> __device__ __forceinline__ void unpack_tri(M &m, const TriFet
   a.u0 = f.q4.z, a.v0 = f.q4.w, a.u1 = f.q5.x, a.v1 = f.q5.y, a.u2 = f.q5.z, a.v2 = f.q5.w;
 }
 // Shade pixel (x,y) of depth z, owner `f`, 8-wide ("V") semantics (src/Rasterizer.cpp:380-389)
-template <class M, int SH = -1, bool L2P150 = false>
+template <class M, int SH = -1, int NL = 0>
 __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
@@ -1049,10 +1071,10 @@ __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const Shade
   v_normalized(m, nx, ny, nz);
   float u = fmaf_(alpha, a.u0, fmaf_(beta, a.u1, gamma * a.u2));
   float v = fmaf_(alpha, a.v0, fmaf_(beta, a.v1, gamma * a.v2));
-  v_shade<M, SH, L2P150>(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2); // zz: the depth k_raster stored (same operations)
+  v_shade<M, SH, NL>(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2); // zz: the depth k_raster stored (same operations)
 }
 // scalar-tail ("S") semantics (src/Rasterizer.cpp:470-492)
-template <class M, int SH = -1, bool L2P150 = false>
+template <class M, int SH = -1, int NL = 0>
 __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
                                               float &r0, float &r1, float &r2) {
   TriAttr a;
@@ -1066,7 +1088,7 @@ __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const Shade
   normalize3(m, nx, ny, nz);
   float u = alpha * a.u0 + beta * a.u1 + gamma * a.u2;
   float v = alpha * a.v0 + beta * a.v1 + gamma * a.v2;
-  s_shade<M, SH, L2P150>(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2);
+  s_shade<M, SH, NL>(m, K, sd, fx, fy, zz, nx, ny, nz, u, v, r0, r1, r2);
 }
 
 #ifdef SRZ_ISA_PROBE
@@ -1084,13 +1106,16 @@ __global__ void probe_v(RenderArgs a, float *o) {
   ShadeDesc sd;
   sd.shader = SRZ_SHADER_TEXTURE, sd.tw = 1024, sd.th = 1024, sd.tex = as_const((const uint32_t *)a.vis);
   float r0, r1, r2;
+#ifndef SRZ_PROBE_SH
+#define SRZ_PROBE_SH -1 /* -1: the generic build's per-pixel generality; 0 / 1 / 2: the FAST variant of that shader type */
+#endif
 #ifdef SRZ_PROBE_S
   FastMath fm;
-  shade_pixel_s<FastMath>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
+  shade_pixel_s<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #else
   FastMath fm;
-  shade_pixel_v<FastMath>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
+  shade_pixel_v<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #endif
   o[threadIdx.x] = r0 + r1 + r2;
@@ -1788,14 +1813,16 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 #define SRZ_SHADE_MINW 4
 #endif
 // Two builds of the same kernel share the persistent walk over the frames' work lists:
-//   FAST     frames whose shading is fully described at compile time up to the shader type: 2 lights, p = 150, every
-//            batch NORMAL / TEXTURE / PHONG (FD_FAST_SHADE, decided on the host).  Per 64-pixel chunk ONE wave-uniform
+//   FAST     (one build per light count 1..4) frames whose shading is fully described at compile time up to the shader type and
+//            the exponent: FASTNL lights, an integer exponent 0..256 (FD_FAST_SHADE + the count, decided on the host).  Per 64-pixel chunk ONE wave-uniform
 //            switch picks the variant compiled for the chunk's shader type (mixed chunks take one pass per type);
 //            optimistic FastMath only — a tile where an operand left the fast range is handed back through redo_list.
 //   generic  every other frame with per-pixel generality (any shader, any light count, any exponent), FastMath first and
 //            the IEEE expansions for a tile that needs them; then the tiles the FAST build handed back, IEEE at once.
-template <bool STATS, bool FAST>
-__global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
+template <bool STATS, int FASTNL, bool BUMPY = false>
+__global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
+  constexpr bool FAST = FASTNL > 0;
+  static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];
@@ -1925,9 +1952,9 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
           // pass per type (the lanes of the other types wait)
           auto run = [&](auto sh) {
             if constexpr (isV)
-              shade_pixel_v<M, decltype(sh)::value, true>(m, K, sd, tf, px, py, r0, r1, r2);
+              shade_pixel_v<M, decltype(sh)::value, FASTNL>(m, K, sd, tf, px, py, r0, r1, r2);
             else
-              shade_pixel_s<M, decltype(sh)::value, true>(m, K, sd, tf, px, py, r0, r1, r2);
+              shade_pixel_s<M, decltype(sh)::value, FASTNL>(m, K, sd, tf, px, py, r0, r1, r2);
           };
           bool todo = true;
           for (unsigned long long tm = __ballot(true); tm != 0ull; tm = __ballot(todo)) {
@@ -1937,8 +1964,15 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
                 run(std::integral_constant<int, SRZ_SHADER_TEXTURE>{});
               else if (sh0 == SRZ_SHADER_PHONG)
                 run(std::integral_constant<int, SRZ_SHADER_PHONG>{});
-              else
+              else if (!BUMPY || sh0 == SRZ_SHADER_NORMAL)
                 run(std::integral_constant<int, SRZ_SHADER_NORMAL>{});
+              else if constexpr (BUMPY) { // (the builds for frames with BUMP / DISPLACEMENT batches: their scalar-tail variants
+                                          // cost ~20 VGPRs more than the other three types need)
+                if (sh0 == SRZ_SHADER_BUMP)
+                  run(std::integral_constant<int, SRZ_SHADER_BUMP>{});
+                else
+                  run(std::integral_constant<int, SRZ_SHADER_DISPLACEMENT>{});
+              }
               todo = false;
             }
           }
@@ -2010,7 +2044,7 @@ __global__ __launch_bounds__(256, FAST ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_
   // frames of 1024^2: a persistent grid of 4096 workgroups dealing every 128th tile of a frame 0.78 ms (one stream), a
   // persistent grid drawing tiles from atomic cursors the same on one stream but 7 % slower on two (it holds every CU slot to
   // its end), this walk 0.73 ms.
-  const uint32_t L = (FAST ? 0u : 8u) + (blockIdx.x & 7u);
+  const uint32_t L = (FAST ? (uint32_t)(FASTNL - 1) + (BUMPY ? 4u : 0u) : SHADE_KIND_GENERIC) * 8u + (blockIdx.x & 7u);
   const uint32_t n_work = (FAST || a.force_generic || a.any_generic) ? as_const(a.work_count)[L * CNT_STRIDE] : 0u;
   const SRZ_CAS uint32_t *list = as_const(a.worklist) + (size_t)L * a.work_cap;
   for (uint32_t w = blockIdx.x >> 3; w < n_work; w += gridDim.x >> 3) {
@@ -2227,7 +2261,7 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
   hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(256), 0, s, a);
 }
 
-void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_fast, bool any_generic, hipStream_t s) {
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, hipStream_t s) {
   if (max_tiles == 0) return;
   // One stream: a LARGE grid (a tile or two per workgroup: in-order hand-out, one-tile tail).  Renders interleaved on several
   // streams (a.other_streams): a grid about as large as the machine's resident capacity, the workgroups striding through the
@@ -2237,14 +2271,23 @@ void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, bool any_
   const uint32_t gcap = env_grid ? env_grid : (a.other_streams ? 2048u : 16384u);
   dim3 grid((std::min(max_tiles, gcap) + 7u) & ~7u); // (a multiple of 8: workgroup b serves list b % 8)
   if (stats) { // (counting runs shade every frame with the generic build: force_generic)
-    hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_shade<true, 0>), grid, dim3(256), 0, s, a);
     return;
   }
-  if (any_fast) hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(256), 0, s, a);
-  // the generic build also serves the tiles the FAST build hands back: when no frame is generic that is normally
+  // one FAST build per (light count, with / without BUMP or DISPLACEMENT batches) some frame of the set has:
+  // fast_mask bit NL = plain, bit 8 + NL = with them
+  if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 16u) hipLaunchKernelGGL((k_shade<false, 4, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x200u) hipLaunchKernelGGL((k_shade<false, 1, true>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x400u) hipLaunchKernelGGL((k_shade<false, 2, true>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x800u) hipLaunchKernelGGL((k_shade<false, 3, true>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x1000u) hipLaunchKernelGGL((k_shade<false, 4, true>), grid, dim3(256), 0, s, a);
+  // the generic build also serves the tiles the FAST builds hand back: when no frame is generic that is normally
   // nothing, and a small grid does
   dim3 ggrid(any_generic ? grid.x : (grid.x < 128u ? grid.x : 128u));
-  hipLaunchKernelGGL((k_shade<false, false>), ggrid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_shade<false, 0>), ggrid, dim3(256), 0, s, a);
 }
 
 bool raster_four_waves(const RenderArgs &a) { return a.n_frames * a.n_local_bands * a.tiles_x <= 4096u; }
@@ -2256,7 +2299,7 @@ void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s)
     once = true;
     int nb = 0, ns = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raster<1>, 64, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, k_shade<false, true>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, (k_shade<false, 2>), 256, 0);
     fprintf(stderr, "[srz] occupancy: k_raster %d waves/CU, k_shade %d WGs/CU\n", nb, ns);
   }
   const uint32_t groups = ((uint32_t)n_frames + 7u) / 8u;

@@ -19,14 +19,16 @@ CRATE_TEX = os.path.join(REPO, "assets/models/Crate/Crate1.png")
 EYE = (0.0, 0.0, 0.9)
 L1 = ((0.9, 0.9, -0.9), (100, 100, 100))
 L2 = ((0.0, 0.8, 0.9), (50, 50, 50))
+L3 = ((-0.9, 0.3, 0.6), (30, 30, 30))  # (a third light for the light-count variants of config 2; not in the README)
 Y = (0, 1, 0)
 
 
 class Workload:
     """A host Scene plus the per-frame model-matrix recipe; frame(i) returns an abi.Frame (post-MVP stream)."""
 
-    def __init__(self, name, width, height, meshes, eye=EYE):
-        """meshes: list of (mesh_name, obj_path, shader_type, translation, scale[, texture_path])."""
+    def __init__(self, name, width, height, meshes, eye=EYE, lights=(L1, L2), p=None):
+        """meshes: list of (mesh_name, obj_path, shader_type, translation, scale[, texture_path]); lights: ((pos, intensity), ...);
+        p: Shader::p for these frames (None: the host layer's static, 150 as the reference ships it)."""
         meshes = [tuple(m) + ((SPOT_TEX,) if len(m) == 5 else ()) for m in meshes]
         self.name, self.width, self.height, self.eye = name, width, height, eye
         self.meshes = [m[:5] for m in meshes]
@@ -40,9 +42,9 @@ class Workload:
                 sc.add_shader(sname, tex, shader)
                 textured[sname] = True
             sc.bind(mname, sname)
-        sc.add_light("Light1", *L1)
-        sc.add_light("Light2", *L2)
-        self.scene = sc
+        for i, l in enumerate(lights):
+            sc.add_light(f"Light{i + 1}", *l)
+        self.scene, self.p = sc, p
         self.textures = {}  # id(ndarray) -> slot
         self.texture_arrays = []
         self.mesh_tex_slot = {}  # mesh name -> texture slot (scene_frame)
@@ -70,7 +72,7 @@ class Workload:
             if needs:
                 self.mesh_tex_slot[mesh[0]] = batches[-1][1]
         ka, ks, p, kh, kn = host.shader_constants()
-        return abi.Frame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), batches, flags, ka, ks, p, kh, kn)
+        return abi.Frame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), batches, flags, ka, ks, p if self.p is None else self.p, kh, kn)
 
     def upload_meshes(self, ctx):
         """Meshes resident on the GPU for the device vertex stage: slot i = i-th registered mesh."""
@@ -95,16 +97,34 @@ class Workload:
             needs = shader in (abi.SHADER_TEXTURE, abi.SHADER_DISPLACEMENT, abi.SHADER_BUMP)
             d.append((slot[name], shader, self.mesh_tex_slot.get(name, 0) if needs else -1, mvp, nm))
         ka, ks, p, kh, kn = host.shader_constants()
-        return abi.SceneFrame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), d, zs, zo, flags, ka, ks, p, kh, kn)
+        return abi.SceneFrame(self.width, self.height, sc.eye, sc.lights().reshape(-1, 2, 3), d, zs, zo, flags, ka, ks, p if self.p is None else self.p, kh, kn)
 
     def upload_textures(self, ctx):
         for slot, tex in enumerate(self.texture_arrays):
             ctx.texture_upload(slot, tex)
 
 
-def spot_texture_1024(shader=abi.SHADER_TEXTURE, size=1024):
+def spot_texture_1024(shader=abi.SHADER_TEXTURE, size=1024, name="spot_texture_1024", **kw):
     """configs[1]: spot_triangulated_good.obj, 1024x1024, TEXTURE shader + 2 point lights."""
-    return Workload("spot_texture_1024", size, size, [("spot", SPOT_OBJ, shader, (0, 0, 0), 0.3)])
+    return Workload(name, size, size, [("spot", SPOT_OBJ, shader, (0, 0, 0), 0.3)], **kw)
+
+
+# configs[1] away from the benchmark's own lights / exponent / shader: what the reference allows at run time (any number of
+# lights, Shader::p a mutable static, five shader types: src/Shader.cpp:7-12,192-640) and bench.py therefore also times
+def spot_texture_1024_3lights():
+    return spot_texture_1024(name="spot_texture_1024_3lights", lights=(L1, L2, L3))
+
+
+def spot_texture_1024_p32():
+    return spot_texture_1024(name="spot_texture_1024_p32", p=32.0)
+
+
+def spot_texture_1024_p7_5():
+    return spot_texture_1024(name="spot_texture_1024_p7.5", p=7.5)  # (not an integer: the generic build of k_shade)
+
+
+def spot_bump_1024():
+    return spot_texture_1024(shader=abi.SHADER_BUMP, name="spot_bump_1024")
 
 
 def spot_bunny_1080p():
@@ -137,5 +157,7 @@ def readme_spot_crate_1024():
                      ("Crate", CRATE_OBJ, abi.SHADER_TEXTURE, (0.28, -0.13, 0.15), 0.1, CRATE_TEX)], eye=(0.0, 0.0, -0.9))
 
 
-WORKLOADS = {"readme_spot_crate_1024": readme_spot_crate_1024, "spot_texture_1024": spot_texture_1024, "spot_bunny_phong_1080p": spot_bunny_1080p,
+WORKLOADS = {"spot_texture_1024_3lights": spot_texture_1024_3lights, "spot_texture_1024_p32": spot_texture_1024_p32,
+             "spot_texture_1024_p7.5": spot_texture_1024_p7_5, "spot_bump_1024": spot_bump_1024,
+             "readme_spot_crate_1024": readme_spot_crate_1024, "spot_texture_1024": spot_texture_1024, "spot_bunny_phong_1080p": spot_bunny_1080p,
              "spot_x16_texture_2048": spot_grid16_2048, "spot_x8_overdraw_4096": spot_overdraw8_4096}
