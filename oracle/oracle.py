@@ -13,17 +13,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "software-rasterizer_amd"))
 from srz import abi  # noqa: E402  (struct definitions only)
 
-_lib = None
+_libs = {}
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        so = os.path.join(_HERE, "libsrz_oracle.so")
+def lib(fast=False):
+    """fast=False: the checker (-O2).  fast=True: the same source at -O3 (bench.py's cpu_baseline only); textures registered
+    with texture_set go to whichever builds are loaded at that time, so load the fast build before registering them."""
+    if fast not in _libs:
+        so = os.path.join(_HERE, "libsrz_oracle_o3.so" if fast else "libsrz_oracle.so")
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
@@ -40,8 +41,8 @@ def lib():
         for n in ("orc_m4_mul", "orc_m4_mulv", "orc_m4_transpose", "orc_m4_inverse", "orc_model_matrix",
                   "orc_look_at_lh", "orc_perspective_lh_no", "orc_ndc_matrix", "orc_clear"):
             getattr(L, n).restype = None
-        _lib = L
-    return _lib
+        _libs[fast] = L
+    return _libs[fast]
 
 
 def _fp(a):
@@ -120,8 +121,10 @@ def texture_set(tex_id, bgr):
     a = np.ascontiguousarray(bgr, dtype=np.uint8)
     h, w, c = a.shape
     assert c == 3
-    rc = lib().orc_texture_set(tex_id, a.ctypes.data, w, h, w * 3)
-    assert rc == 0, rc
+    lib()
+    for L in _libs.values():  # (every loaded build keeps its own table)
+        rc = L.orc_texture_set(tex_id, a.ctypes.data, w, h, w * 3)
+        assert rc == 0, rc
 
 
 def new_planes(w, h):
@@ -144,18 +147,18 @@ def draw_rows(frame, planes, row0, row1):
     return lib().orc_draw_rows(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(row0), int(row1))
 
 
-def draw_omp(frame, planes, band=16, threads=0):
+def draw_omp(frame, planes, band=16, threads=0, fast=False):
     z, c0, c1, c2 = planes
     n = C.c_int(0)
-    rc = lib().orc_draw_omp(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(band), C.byref(n), int(threads))
+    rc = lib(fast).orc_draw_omp(C.byref(frame.c), _fp(z), _fp(c0), _fp(c1), _fp(c2), int(band), C.byref(n), int(threads))
     return rc, n.value
 
 
-def draw_frames_omp(frames, n_total, threads=0):
+def draw_frames_omp(frames, n_total, threads=0, fast=False):
     """clear + draw of n_total frames (round-robin over `frames`), whole frames per OpenMP thread → (rc, threads used)."""
     arr = (C.POINTER(abi.SrzFrame) * len(frames))(*[C.pointer(f.c) for f in frames])
     n = C.c_int(0)
-    rc = lib().orc_draw_frames_omp(arr, len(frames), int(n_total), int(threads), C.byref(n))
+    rc = lib(fast).orc_draw_frames_omp(arr, len(frames), int(n_total), int(threads), C.byref(n))
     return rc, n.value
 
 
