@@ -278,33 +278,44 @@ def make_comm(ctx, dist, torch, rank, world):
     return comm, None
 
 
-def time_multi_gpu(case, comm, dist, steps, warmup, fence, exchange="planes", no_overlap=False):
+def time_multi_gpu(case, comm, dist, steps, warmup, fence, exchange="planes", no_overlap=False, layout="shards", rank=0):
     """N > 1 (also runs at world 1 with a one-rank communicator — tests/test_gpu_exchange.py drives it there, so the scaling
-    run is not this code's first execution): render on one stream, exchange (all-gather + de-interleave) on another,
-    double-buffered: the exchange of step k runs while step k+1 renders.  → (dt, kernel times, per-step list, multi dict)"""
+    run is not this code's first execution): render on one stream, exchange on another, double-buffered: the exchange of step
+    k runs while step k+1 renders.  layout "shards": the rank renders (or resolves) straight into its slot of the gathered
+    buffer and the exchange is ONE in-place all-gather, no second pass (result in rank-major shard order,
+    srz_frameset_allgather_inplace); "rows": all-gather into a staging buffer + one HIP de-interleave pass (row-major frames).
+    → (dt, kernel times, per-step list, multi dict)"""
     from srz import abi, parallel
     torch, ctx, fs, world = case.torch, case.ctx, case.fs, case.world
     what = abi.EXCHANGE_PLANES if exchange == "planes" else abi.EXCHANGE_BGR8
     bpr = fs.local_rows // 32 if world > 1 else None
     rows_full = bpr * world * 32 if world > 1 else fs.local_rows
-    if exchange == "planes":
-        shard = case.out
-        full_shape, dtype = (case.n_frames, 4, rows_full, fs.width), torch.float32
-    else:  # display()'s 8-bit image: one "plane" of W*3 bytes per row
-        shard = [torch.empty((case.n_frames, 1, fs.local_rows, fs.width * 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
-        full_shape, dtype = (case.n_frames, 1, rows_full, fs.width * 3), torch.uint8
-    gathered = [torch.empty((world,) + tuple(shard[0].shape), dtype=dtype, device="cuda") for _ in range(2)]
-    full = [torch.empty(full_shape, dtype=dtype, device="cuda") for _ in range(2)]
+    shard_shape, dtype = ((case.n_frames, 4, fs.local_rows, fs.width), torch.float32) if exchange == "planes" else \
+                         ((case.n_frames, 1, fs.local_rows, fs.width * 3), torch.uint8)  # (display()'s image: one "plane" of W*3 bytes per row)
+    gathered = [torch.empty((world,) + shard_shape, dtype=dtype, device="cuda") for _ in range(2)]
+    if layout == "shards":  # this rank's shard IS its slot of the gathered buffer
+        shard = [g[rank] for g in gathered]
+        full = gathered
+        planes = shard if exchange == "planes" else case.out
+    else:
+        shard = case.out if exchange == "planes" else [torch.empty(shard_shape, dtype=dtype, device="cuda") for _ in range(2)]
+        full = [torch.empty((case.n_frames, shard_shape[1], rows_full, shard_shape[3]), dtype=dtype, device="cuda") for _ in range(2)]
+        planes = case.out
     rq = parallel.TorchQueue()
     xq = rq if no_overlap else parallel.TorchQueue()
 
     def render(b):
-        fs.render(case.out[b].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, rq.handle)
+        fs.render(planes[b].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, rq.handle)
         if exchange == "bgr8":
-            fs.resolve8(case.out[b].data_ptr(), shard[b].data_ptr(), shard[b].numel(), rq.handle)
+            fs.resolve8(planes[b].data_ptr(), shard[b].data_ptr(), shard[b].numel(), rq.handle)
 
     def do_exchange(b):
-        if comm is not None:
+        if layout == "shards":
+            if comm is not None:
+                fs.allgather_inplace(comm, gathered[b].data_ptr(), what, xq.handle)
+            elif world > 1:  # (torch.distributed's RCCL on the current = exchange stream, in place)
+                dist.all_gather_into_tensor(gathered[b].view(-1), shard[b].reshape(-1))
+        elif comm is not None:
             fs.allgather(comm, shard[b].data_ptr(), gathered[b].data_ptr(), full[b].data_ptr(), what, xq.handle)
         else:  # (torch.distributed's RCCL on the current = exchange stream, then the HIP de-interleave)
             dist.all_gather_into_tensor(gathered[b].view(-1), shard[b].reshape(-1))
@@ -339,14 +350,15 @@ def time_multi_gpu(case, comm, dist, steps, warmup, fence, exchange="planes", no
         dt, x_alone = float(tt[0]), float(tt[1]) * 1e3
     step_ms = dt / steps * 1e3
     shard_bytes = shard[0].numel() * shard[0].element_size()
-    multi = {"exchange": exchange, "behind_c_abi": comm is not None, "overlapped": not no_overlap,
+    multi = {"exchange": exchange, "layout": layout, "second_pass": layout != "shards", "behind_c_abi": comm is not None, "overlapped": not no_overlap,
              "step_ms": step_ms, "render_ms_per_step": kt["total_ms"], "exchange_alone_ms_per_step": x_alone,
              "hidden_ms_per_step": max(0.0, kt["total_ms"] + x_alone - step_ms),
              "bytes_sent_per_rank_per_step": shard_bytes, "bytes_received_per_rank_per_step": (world - 1) * shard_bytes,
              "predicted_exchange_ms_at_xgmi_peak": shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3,
-             "note": "exchange = srz_frameset_allgather: ncclAllGather of every rank's band shard (each rank sends its shard "
-                     "once to each of the N-1 peers, one xGMI link per peer: time >= shard bytes / 153 GB/s) + one HIP "
-                     "de-interleave pass; step k's exchange runs while step k+1 renders",
+             "note": "exchange = ncclAllGather of every rank's band shard (each rank sends its shard once to each of the N-1 peers, one "
+                     "xGMI link per peer: time >= shard bytes / 153 GB/s); layout shards: in place, nothing else "
+                     "(srz_frameset_allgather_inplace; frames stay in rank-major shard order), layout rows: + one HIP "
+                     "de-interleave pass into row-major frames (srz_frameset_allgather); step k's exchange runs while step k+1 renders",
              "last_full": full[(steps - 1) % 2]}
     return dt, kt, [], multi
 
@@ -422,6 +434,9 @@ def main():
     ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
                     help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
                          "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
+    ap.add_argument("--exchange-layout", choices=["shards", "rows"], default="shards",
+                    help="N>1 only. shards: render into the rank's slot of the gathered buffer, ONE in-place all-gather, no second "
+                         "pass (frames stay in rank-major shard order); rows: all-gather + a HIP de-interleave pass (row-major frames)")
     ap.add_argument("--lanes", type=int, default=0,
                     help="N=1: the batch is rendered as this many runs of whole frames on streams of their own "
                          "(srz.parallel.LaneRenderer: consecutive steps overlap at their edges); 1 = one frameset on one "
@@ -474,7 +489,7 @@ def main():
         dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes)
     else:
         dt, kt, per_step, multi = time_multi_gpu(case, comm, dist if world > 1 else None, args.steps, args.warmup, fence, args.exchange,
-                                                 args.no_overlap)
+                                                 args.no_overlap, args.exchange_layout, rank)
         multi.pop("last_full")
         if comm_note:
             multi["fallback"] = comm_note
@@ -505,7 +520,7 @@ def main():
                        "frames_per_step": case.n_frames, "frames_per_step_per_gpu": args.frames,
                        "triangles_per_frame": case.tris_per_frame, "lights": len(case.frames[0].lights), "scope": args.scope,
                        "sharding": "whole frames on 1 GPU" if world == 1 else
-                       f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {args.exchange} + de-interleave (timed)"},
+                       f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {args.exchange}, layout {args.exchange_layout} (timed)"},
             "mfragments_per_sec": rec["mfragments_per_sec"], "fragments_per_frame": rec["fragments_per_frame"],
             "visible_pixels_per_frame": rec["visible_pixels_per_frame"],
             "ms_per_step_p10_median_p90": rec["ms_per_step_p10_median_p90"], "us_per_frame_median": rec["us_per_frame_median"],

@@ -37,8 +37,9 @@ extern "C" {
  *   2  srz_draw_batch, scenesets, targets
  *   3  `stream` arguments: NULL = the ctx's own stream, SRZ_STREAM_NULL = HIP's null stream (was: NULL = null stream);
  *      srz_comm_*, srz_frameset_allgather / _deinterleave / _exchange_bytes, srz_kernel_time_samples
+ *   4  srz_frameset_allgather_inplace, srz_frameset_gathered_row_offset, srz_frameset_read_gathered_frame
  */
-#define SRZ_ABI_VERSION 3
+#define SRZ_ABI_VERSION 4
 
 /* error codes */
 #define SRZ_OK 0
@@ -239,6 +240,20 @@ int srz_frameset_allgather(srz_ctx *ctx, srz_comm *comm, const srz_frameset *fs,
                            void *d_full, int what, void *stream);
 int srz_frameset_deinterleave(srz_ctx *ctx, const srz_frameset *fs, const void *d_gathered, void *d_full, int what,
                               void *stream);
+/* The exchange WITHOUT a second pass.  The rank renders (srz_frameset_render) or resolves (srz_frameset_resolve8) its shard
+ * directly at  d_gathered + rank * srz_frameset_exchange_bytes()  and this call is one IN-PLACE ncclAllGather that fills in the
+ * other ranks' shards around it: no staging copy, no de-interleave kernel, nothing but the xGMI transfers.  The result stays in
+ * the all-gather's own order, "rank-major shards":
+ *     [rank][frame][plane: z,c0,c1,c2 | 1][bands_per_rank * 32 rows][row bytes]
+ * row y of a frame lives in the shard of rank (y / 32) % world at local row (y / 32 / world) * 32 + y % 32:
+ * srz_frameset_gathered_row_offset() returns that row's byte offset in d_gathered, and srz_frameset_read_gathered_frame() brings
+ * one frame to the host as row-major planes ([4][H][W] float, or [H][W][3] bytes for SRZ_EXCHANGE_BGR8), de-interleaving in the
+ * device→host copy itself (one strided copy per rank and plane).  A device-side consumer that needs row-major planes uses
+ * srz_frameset_allgather (all-gather + one HIP pass) instead.  With world = 1 the call does nothing. */
+int srz_frameset_allgather_inplace(srz_ctx *ctx, srz_comm *comm, const srz_frameset *fs, void *d_gathered, int what, void *stream);
+size_t srz_frameset_gathered_row_offset(const srz_ctx *ctx, const srz_frameset *fs, int what, int frame, int plane, int row);
+int srz_frameset_read_gathered_frame(srz_ctx *ctx, const srz_frameset *fs, const void *d_gathered, int what, int frame,
+                                     void *host_out, void *stream);
 
 /* ---- device-resident framebuffer = RenderingPipeline's m_zBuffer + m_channels kept in HBM between calls ----------
  * clear(Color|Depth) immediately followed by a draw costs nothing (fused into the raster kernel); planes come back to

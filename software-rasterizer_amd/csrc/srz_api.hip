@@ -1313,6 +1313,63 @@ int srz_frameset_allgather(srz_ctx *ctx, srz_comm *c, const srz_frameset *fs, co
   return srz_frameset_deinterleave(ctx, fs, d_gathered, d_full, what, stream);
 }
 
+int srz_frameset_allgather_inplace(srz_ctx *ctx, srz_comm *c, const srz_frameset *fs, void *d_gathered, int what, void *stream) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!c || !fs || !d_gathered) return fail(ctx, SRZ_E_INVALID, "srz_frameset_allgather_inplace: null argument");
+  if (fs->shard_world != c->world || fs->shard_rank != c->rank)
+    return fail(ctx, SRZ_E_INVALID, "srz_frameset_allgather_inplace: the frameset was not created under this communicator's shard");
+  const size_t bytes = srz_frameset_exchange_bytes(ctx, fs, what);
+  if (bytes == 0 || (what != SRZ_EXCHANGE_PLANES && what != SRZ_EXCHANGE_BGR8)) return fail(ctx, SRZ_E_INVALID, "srz_frameset_allgather_inplace: bad exchange kind");
+  if (c->world == 1) return SRZ_OK; // one rank: its shard is the whole buffer
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  // in place: sendbuff == recvbuff + rank * count (the form NCCL / RCCL document for an all-gather without a copy of the own part)
+  const int rc = rccl().AllGather(static_cast<const uint8_t *>(d_gathered) + (size_t)c->rank * bytes, d_gathered, bytes, /* ncclUint8 */ 1, c->comm, s);
+  if (rc != 0) return fail(ctx, SRZ_E_NODEVICE, "ncclAllGather (in place): " + rccl_err(rc));
+  return SRZ_OK;
+}
+
+size_t srz_frameset_gathered_row_offset(const srz_ctx *ctx, const srz_frameset *fs, int what, int frame, int plane, int row) {
+  if (!fs || frame < 0 || frame >= fs->n_frames || row < 0 || row >= fs->height) return (size_t)-1;
+  const size_t planes = what == SRZ_EXCHANGE_BGR8 ? 1u : 4u;
+  if (plane < 0 || (size_t)plane >= planes) return (size_t)-1;
+  const size_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (size_t)fs->width * 3u : (size_t)fs->width * sizeof(float);
+  const size_t band = (size_t)row / BAND, world = (size_t)fs->shard_world;
+  const size_t rank = band % world, local_row = (band / world) * BAND + (size_t)row % BAND;
+  const size_t shard_rows = fs->shard_world == 1 ? (size_t)fs->height : (size_t)fs->bands_per_rank * BAND;
+  return (((rank * (size_t)fs->n_frames + (size_t)frame) * planes + (size_t)plane) * shard_rows + local_row) * row_bytes;
+}
+
+int srz_frameset_read_gathered_frame(srz_ctx *ctx, const srz_frameset *fs, const void *d_gathered, int what, int frame, void *host_out,
+                                     void *stream) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (!fs || !d_gathered || !host_out || frame < 0 || frame >= fs->n_frames || (what != SRZ_EXCHANGE_PLANES && what != SRZ_EXCHANGE_BGR8))
+    return fail(ctx, SRZ_E_INVALID, "srz_frameset_read_gathered_frame: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const size_t planes = what == SRZ_EXCHANGE_BGR8 ? 1u : 4u;
+  const size_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (size_t)fs->width * 3u : (size_t)fs->width * sizeof(float);
+  const size_t band_bytes = row_bytes * BAND, world = (size_t)fs->shard_world;
+  const size_t n_bands = ((size_t)fs->height + BAND - 1) / BAND;
+  // per (rank, plane): that rank's bands of the plane are consecutive in its shard and world bands apart in the host image —
+  // ONE strided copy (the last band of a frame whose height is not a multiple of 32 is copied on its own: it is short)
+  for (size_t p = 0; p < planes; ++p)
+    for (size_t r = 0; r < world && r < n_bands; ++r) {
+      const size_t n_local = (n_bands - r + world - 1) / world;
+      const size_t last_band = r + (n_local - 1) * world;
+      const size_t last_rows = std::min<size_t>(BAND, (size_t)fs->height - last_band * BAND); // (short only for the frame's last band)
+      const size_t full_bands = last_rows == BAND ? n_local : n_local - 1;
+      const uint8_t *src = static_cast<const uint8_t *>(d_gathered) + srz_frameset_gathered_row_offset(ctx, fs, what, frame, (int)p, (int)(r * BAND));
+      uint8_t *dst = static_cast<uint8_t *>(host_out) + (p * (size_t)fs->height + r * BAND) * row_bytes;
+      if (full_bands)
+        HIP_TRY(ctx, hipMemcpy2DAsync(dst, world * band_bytes, src, band_bytes, band_bytes, full_bands, hipMemcpyDeviceToHost, s));
+      if (full_bands < n_local)
+        HIP_TRY(ctx, hipMemcpyAsync(dst + full_bands * world * band_bytes, src + full_bands * band_bytes, last_rows * row_bytes, hipMemcpyDeviceToHost, s));
+    }
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return SRZ_OK;
+}
+
 int srz_sync(srz_ctx *ctx) {
   if (!ctx) return SRZ_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -20,7 +20,8 @@ EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "sr
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
            "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch",
            "srz_comm_unique_id", "srz_comm_create", "srz_comm_destroy", "srz_frameset_exchange_bytes", "srz_frameset_allgather",
-           "srz_frameset_deinterleave"]
+           "srz_frameset_deinterleave", "srz_frameset_allgather_inplace", "srz_frameset_gathered_row_offset",
+           "srz_frameset_read_gathered_frame"]
 
 
 class SrzError(RuntimeError):
@@ -82,6 +83,10 @@ def lib():
         L.srz_frameset_exchange_bytes.restype = C.c_size_t
         L.srz_frameset_allgather.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
         L.srz_frameset_deinterleave.argtypes = [vp, vp, vp, vp, C.c_int, vp]
+        L.srz_frameset_allgather_inplace.argtypes = [vp, vp, vp, vp, C.c_int, vp]
+        L.srz_frameset_gathered_row_offset.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.srz_frameset_gathered_row_offset.restype = C.c_size_t
+        L.srz_frameset_read_gathered_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
         _lib = L
     return _lib
 
@@ -135,6 +140,22 @@ class FrameSet:
         """RCCL all-gather of this rank's shard + de-interleave into row-major frames (srz_frameset_allgather)."""
         self.ctx._check(lib().srz_frameset_allgather(self.ctx.h, comm.h, self.h, C.c_void_p(d_shard_ptr), C.c_void_p(d_gathered_ptr),
                                                      C.c_void_p(d_full_ptr), what, _stream(stream)))
+
+    def allgather_inplace(self, comm, d_gathered_ptr, what=abi.EXCHANGE_PLANES, stream=None):
+        """the exchange without a second pass: this rank's shard was rendered at d_gathered + rank * exchange_bytes; ONE in-place
+        RCCL all-gather fills in the others.  Layout: [rank][frame][plane][bands_per_rank*32][row] (gathered_row_offset)"""
+        self.ctx._check(lib().srz_frameset_allgather_inplace(self.ctx.h, comm.h, self.h, C.c_void_p(d_gathered_ptr), what, _stream(stream)))
+
+    def gathered_row_offset(self, frame, plane, row, what=abi.EXCHANGE_PLANES):
+        return int(lib().srz_frameset_gathered_row_offset(self.ctx.h, self.h, what, frame, plane, row))
+
+    def read_gathered_frame(self, d_gathered_ptr, frame, what=abi.EXCHANGE_PLANES, stream=None):
+        """one frame of a gathered buffer as row-major host planes ([4,H,W] float32, or [H,W,3] uint8), de-interleaved by the
+        device→host copies"""
+        out = np.empty((4, self.height, self.width), np.float32) if what == abi.EXCHANGE_PLANES else np.empty((self.height, self.width, 3), np.uint8)
+        self.ctx._check(lib().srz_frameset_read_gathered_frame(self.ctx.h, self.h, C.c_void_p(d_gathered_ptr), what, frame,
+                                                                out.ctypes.data_as(C.c_void_p), _stream(stream)))
+        return out
 
     def deinterleave(self, d_gathered_ptr, d_full_ptr, what=abi.EXCHANGE_PLANES, stream=None):
         self.ctx._check(lib().srz_frameset_deinterleave(self.ctx.h, self.h, C.c_void_p(d_gathered_ptr), C.c_void_p(d_full_ptr), what,

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-SRZ_ABI_VERSION = 3  # = include/srz.h; srz.lib() refuses a library that reports another one
+SRZ_ABI_VERSION = 4  # = include/srz.h; srz.lib() refuses a library that reports another one
 SRZ_OK = 0
 SRZ_E_INVALID, SRZ_E_NODEVICE, SRZ_E_NOMEM, SRZ_E_TEXTURE, SRZ_E_PRIMITIVE = -1, -2, -3, -4, -5
 SHADER_NORMAL, SHADER_TEXTURE, SHADER_PHONG, SHADER_DISPLACEMENT, SHADER_BUMP = 0, 1, 2, 3, 4

@@ -39,6 +39,20 @@ def deinterleave(gathered, world, out=None):
     return out
 
 
+def gathered_row(gathered, frame, plane, row, world):
+    """the row `row` of a frame inside a rank-major gathered buffer [world, frames, planes, bands_per_rank*32, W] (the layout
+    srz_frameset_allgather_inplace leaves; = srz_frameset_gathered_row_offset)"""
+    band = row // BAND
+    return gathered[band % world, frame, plane, (band // world) * BAND + row % BAND]
+
+
+def all_gather_inplace(gathered, rank, group=None):
+    """the exchange without a second pass: gathered[rank] already holds this rank's shard; one in-place all-gather"""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(gathered.view(-1), gathered[rank].reshape(-1), group=group)
+    return gathered
+
+
 def all_gather_frames(shard, world, gathered, full=None, group=None):
     """shard: this rank's [frames,4,local_rows,W] tensor → every rank gets every full frame."""
     import torch.distributed as dist

@@ -85,8 +85,8 @@ def test_communicator_of_one_rank(orc):
     ctx.close()
 
 
-@pytest.mark.parametrize("exchange", ["planes", "bgr8"])
-def test_bench_multi_gpu_step_loop_at_world_one(orc, exchange):
+@pytest.mark.parametrize("exchange,layout", [("planes", "shards"), ("bgr8", "shards"), ("planes", "rows"), ("bgr8", "rows")])
+def test_bench_multi_gpu_step_loop_at_world_one(orc, exchange, layout):
     """bench.py's N > 1 branch (render stream + exchange stream, double-buffered ExchangePipeline, srz_frameset_allgather
     through a real RCCL communicator, the exchange-alone pass) driven at world 1, so that the 8-GPU scaling run is not that
     code's first execution; the last step's full frames must be the oracle's."""
@@ -101,10 +101,12 @@ def test_bench_multi_gpu_step_loop_at_world_one(orc, exchange):
     def fence():
         torch.cuda.synchronize()
 
-    dt, kt, per_step, multi = bench.time_multi_gpu(case, comm, None, steps=3, warmup=2, fence=fence, exchange=exchange)
-    assert dt > 0 and kt["launches"] == 3 and multi["behind_c_abi"] and multi["overlapped"]
+    dt, kt, per_step, multi = bench.time_multi_gpu(case, comm, None, steps=3, warmup=2, fence=fence, exchange=exchange, layout=layout)
+    assert dt > 0 and kt["launches"] == 3 and multi["behind_c_abi"] and multi["overlapped"] and multi["second_pass"] == (layout == "rows")
     assert multi["bytes_sent_per_rank_per_step"] == case.fs.exchange_bytes(abi.EXCHANGE_PLANES if exchange == "planes" else abi.EXCHANGE_BGR8)
     full = multi.pop("last_full").cpu().numpy()
+    if layout == "shards":
+        full = full[0]  # (one rank: its shard is the frame)
     import json
     json.dumps(multi)  # (what is left goes into bench.py's JSON line)
     for i in (0, 5):
@@ -166,6 +168,43 @@ def test_baseline_configs_4_and_5_as_specified_eight_way_sharded(orc, cfg, frame
         got = full[i, :, :size].cpu().numpy()
         assert np.array_equal(bits(got), bits(refs[i])), (cfg, i)
         assert np.array_equal(full8[i, 0, :size].cpu().numpy().reshape(size, size, 3), orc.resolve8(tuple(refs[i]))), (cfg, i)
+    # the exchange WITHOUT the second pass leaves exactly `gathered` (every rank rendered into its own slot above): rows are
+    # found by srz_frameset_gathered_row_offset, and a frame comes to the host de-interleaved by the copies themselves
+    gflat, g8flat = gathered.view(torch.uint8).reshape(-1), g8.reshape(-1)
+    for (p, y) in ((0, 0), (1, 31), (2, 32), (3, size - 1), (0, 32 * 8 + 5), (2, 32 * 13 + 17)):
+        off = fs.gathered_row_offset(0, p, y)
+        row = gflat[off: off + size * 4].view(torch.float32).cpu().numpy()
+        assert np.array_equal(bits(row), bits(refs[0][p][y])), (cfg, p, y)
+        assert torch.equal(parallel.gathered_row(gathered, 0, p, y, world), gathered.view(torch.uint8).reshape(-1)[off: off + size * 4].view(torch.float32))
+    off8 = fs.gathered_row_offset(0, 0, 77, abi.EXCHANGE_BGR8)
+    assert np.array_equal(g8flat[off8: off8 + size * 3].cpu().numpy().reshape(size, 3), orc.resolve8(tuple(refs[0]))[77])
+    assert fs.gathered_row_offset(0, 4, 0) == 2 ** 64 - 1 and fs.gathered_row_offset(0, 0, size) == 2 ** 64 - 1   # out of range
+    host = fs.read_gathered_frame(gathered.data_ptr(), 0)
+    assert np.array_equal(bits(host), bits(refs[0])), cfg
+    host8 = fs.read_gathered_frame(g8.data_ptr(), 0, abi.EXCHANGE_BGR8)
+    assert np.array_equal(host8, orc.resolve8(tuple(refs[0]))), cfg
+    fs.close(), ctx.close()
+
+
+def test_read_gathered_frame_with_a_short_last_band(orc):
+    """a frame height that is not a multiple of 32 (1080 = 33 bands + 24 rows), three ranks: the strided device→host copies of
+    srz_frameset_read_gathered_frame must place every band, the short one included"""
+    import srz
+    world, w, h = 3, 320, 200
+    frames = [scenes.config3(4, w, h)]
+    ref = np.stack(orc.draw(frames[0])[1])
+    lay = parallel.shard_layout(h, 0, world)
+    gathered = torch.zeros((world, 1, 4, lay["local_rows"], w), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        ctx = srz.Context(0, r, world)
+        ctx.texture_upload(0, scenes.spot_texture())
+        fs = ctx.frameset(frames)
+        fs.render(gathered[r].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if r + 1 < world:
+            fs.close(), ctx.close()
+    host = fs.read_gathered_frame(gathered.data_ptr(), 0)
+    assert np.array_equal(bits(host), bits(ref))
     fs.close(), ctx.close()
 
 
@@ -226,6 +265,15 @@ def _two_rank_worker(rank, world, port, q):
                   snaps.append(full[b].clone())
           pipe.drain()
           torch.cuda.synchronize()
+          # the exchange without the second pass: render into the own slot of the gathered buffer, one in-place all-gather
+          g = torch.zeros((world,) + tuple(fs0.out_shape), dtype=torch.float32, device="cuda")
+          sets[1].render(g[rank].data_ptr(), fs0.out_bytes, abi.FUSED_CLEAR, rq.handle)
+          rq.drain()
+          fs0.allgather_inplace(comm, g.data_ptr(), abi.EXCHANGE_PLANES, xq.handle)
+          xq.drain()
+          for i in range(nf):
+              ref = np.stack(oracle.draw(scenes.config2(3 + i, size=size))[1])
+              ok = ok and np.array_equal(fs0.read_gathered_frame(g.data_ptr(), i).view(np.uint32), ref.view(np.uint32))
           for k in range(steps):
               got = snaps[k].cpu().numpy()[:, :, :size]
               for i in range(nf):

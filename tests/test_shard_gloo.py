@@ -54,6 +54,15 @@ def _worker(rank, world, port, height, width, q):
         full8 = parallel.all_gather_frames(shard8, world, gathered8)
         ref8 = to_bgr8(torch.from_numpy(np.stack(full_ref)))
         ok = ok and torch.equal(full8[:, :, :height], ref8) and bool((ref8 > 0).any())
+        # the exchange without the second pass: the shard sits in its own slot of the gathered buffer, ONE in-place all-gather,
+        # rows located by the rank-major rule of srz_frameset_gathered_row_offset
+        g2 = torch.zeros((world,) + tuple(shard.shape), dtype=torch.float32)
+        g2[rank] = shard
+        parallel.all_gather_inplace(g2, rank)
+        for fi in range(len(frames)):
+            for p in range(4):
+                for y in (0, 31, 32, 63, height - 1, height // 2):
+                    ok = ok and np.array_equal(parallel.gathered_row(g2, fi, p, y, world).numpy().view(np.uint32), full_ref[fi][p][y].view(np.uint32))
         q.put((rank, ok, tuple(full.shape)))
     finally:
         dist.destroy_process_group()
