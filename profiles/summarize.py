@@ -29,7 +29,7 @@ def kernel_of(name):
     if "<true" in name:  # counting variants (run once, outside the timed region)
         return None
     if "k_shade" in name:
-        return "k_shade_generic" if "k_shade<false, 0>" in name else "k_shade_fast"
+        return "k_shade_generic" if "k_shade<false, 0," in name else "k_shade_fast"  # (FAST builds: <false, lights 1..4, bumpy>)
     for k in KERNELS:
         if k in name:
             return k
