@@ -391,6 +391,51 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 }
 
 // ================================================================================================================
+// Tight rectangles.  The reference tests every pixel of a triangle's bounding box; a pixel outside the triangle fails the test
+// and leaves no trace, so pixels that are CERTAINLY outside need not be tested — and a tile or band the triangle certainly
+// misses need not list it.  slab_extent gives the extent along u of (triangle ∩ slab lo <= w <= hi), (u, w) = (x, y) or (y, x),
+// from the vertices inside the slab and the edges' crossings of its two bounds (+inf / -inf when the triangle misses it).
+// CONSERVATIVE: a pixel can pass the rounded inside tests (cover_v / cover_s) only within a distance eps of the true triangle —
+// the edge functions are wrong by < 2^-21 D^2 (D = the vertices' extent: every operand is a difference within the box), the
+// barycentrics by that over |area2| — so with D^2 <= 256 |area2| eps < 2^-11 D; tight_margin returns false otherwise (slivers,
+// non-finite or huge coordinates: the plain box is used).  Slabs and extents are widened by m = D / 512 + 1 / 64, which also
+// covers v_rcp's error in the crossings (2^-22 of a length <= D).
+// ================================================================================================================
+__device__ __forceinline__ bool tight_margin(float ax, float ay, float bx, float by, float cx, float cy, float area2, float &m) {
+  const float D = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ax, bx), cx) - __builtin_fminf(__builtin_fminf(ax, bx), cx),
+                                  __builtin_fmaxf(__builtin_fmaxf(ay, by), cy) - __builtin_fminf(__builtin_fminf(ay, by), cy));
+  m = __builtin_fmaf(D, 0.001953125f, 0.015625f);
+  return D * D <= 256.0f * __builtin_fabsf(area2) && D <= 1048576.0f; // (false for NaN / inf)
+}
+__device__ __forceinline__ void slab_extent(float au, float aw, float bu, float bw, float cu, float cw, float lo, float hi, float &mn,
+                                            float &mx) {
+  mn = __builtin_inff(), mx = -__builtin_inff();
+  auto vertex = [&](float u, float w) {
+    const bool in = (w >= lo) & (w <= hi);
+    mn = in ? __builtin_fminf(mn, u) : mn, mx = in ? __builtin_fmaxf(mx, u) : mx;
+  };
+  auto edge = [&](float pu, float pw, float qu, float qw) {
+    const float inv = __builtin_amdgcn_rcpf(pw - qw), du = qu - pu;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float bound = k ? hi : lo, dp = pw - bound, dq = qw - bound;
+      const float u = __builtin_fmaf(du, dp * inv, pu); // (pw == qw: no crossing, the NaN / inf is not selected)
+      const bool cross = (dp < 0.0f) != (dq < 0.0f);
+      mn = cross ? __builtin_fminf(mn, u) : mn, mx = cross ? __builtin_fmaxf(mx, u) : mx;
+    }
+  };
+  vertex(au, aw), vertex(bu, bw), vertex(cu, cw);
+  edge(au, aw, bu, bw), edge(bu, bw, cu, cw), edge(cu, cw, au, aw);
+}
+// the integer range [i0, i1] clipped to ceil(mn - m) .. floor(mx + m) (as floats first: the conversions stay in range); an
+// extent that misses the range gives i0 > i1
+__device__ __forceinline__ void clip_range(int &i0, int &i1, float mn, float mx, float m) {
+  const float f0 = (float)i0, f1 = (float)i1;
+  i0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_ceilf(mn - m), f0), f1 + 1.0f);
+  i1 = (int)__builtin_fmaxf(__builtin_fminf(__builtin_floorf(mx + m), f1), f0 - 1.0f);
+}
+
+// ================================================================================================================
 // bucket_group — the O(triangles) half of the binning, shared by k_setup and k_chunks: the GROUP_TRIS triangles of one group
 // (GROUP_K per thread: triangle g * GROUP_TRIS + k * 256 + tid) are sorted by the local 32-row bands their bounding boxes reach, in LDS:
 //   count  one LDS atomic per (triangle, band)             scan  exclusive prefix over the bands (wave 0, DPP)
@@ -400,8 +445,8 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // DESC_RAW in every band instead: k_bin's band workgroups then walk its bounding boxes themselves.
 // ================================================================================================================
 __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t nlb, const uint32_t group, const uint32_t t0,
-                                             const BBox (&bb)[GROUP_K], const bool (&keep)[GROUP_K], uint32_t *s_cnt, uint32_t *s_off,
-                                             uint32_t *s_fill, uint32_t *s_misc) {
+                                             const BBox (&bb)[GROUP_K], const bool (&keep)[GROUP_K], const float (*P)[9],
+                                             uint32_t *s_cnt, uint32_t *s_off, uint32_t *s_fill, uint32_t *s_misc) {
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int world = a.shard_world, rank = a.shard_rank;
   for (uint32_t i = (uint32_t)tid; i < nlb; i += 256u) s_cnt[i] = 0u;
@@ -439,7 +484,25 @@ __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t
 #pragma unroll
     for (int k = 0; k < (int)GROUP_K; ++k) {
       const uint32_t xr = (uint32_t)((int)bb[k].sx >> 5) | ((uint32_t)((int)bb[k].ex >> 5) << 16);
-      for (int j = 0; j < nb[k]; ++j) ent[atomicAdd(&s_fill[lb0[k] + j], 1u)] = make_uint2(t0 + (uint32_t)k * 256u + (uint32_t)tid, xr);
+      // (P: the positions, where the caller has them in registers) the tile range of a band is tightened to the triangle's
+      // x-extent inside the band's rows (tight_margin): the tiles in the corners of a large bounding box drop out of the lists
+      float m = 0.0f;
+      const bool tight = P != nullptr && nb[k] > 0 &&
+                         tight_margin(P[k][0], P[k][1], P[k][3], P[k][4], P[k][6], P[k][7],
+                                      (P[k][3] - P[k][0]) * (P[k][7] - P[k][1]) - (P[k][4] - P[k][1]) * (P[k][6] - P[k][0]), m);
+      for (int j = 0; j < nb[k]; ++j) {
+        uint32_t xr_j = xr;
+        if (tight) {
+          const int b = (lb0[k] + j) * world + rank;
+          int X0 = bb[k].sx, X1 = bb[k].ex;
+          float mn, mx;
+          slab_extent(P[k][0], P[k][1], P[k][3], P[k][4], P[k][6], P[k][7], (float)max(b * BAND, (int)bb[k].sy) - m,
+                      (float)min(b * BAND + BAND - 1, (int)bb[k].ey) + m, mn, mx);
+          clip_range(X0, X1, mn, mx, m);
+          xr_j = X0 <= X1 ? ((uint32_t)(X0 >> 5) | ((uint32_t)(X1 >> 5) << 16)) : 1u; // (1: tiles 1 .. 0 = none)
+        }
+        ent[atomicAdd(&s_fill[lb0[k] + j], 1u)] = make_uint2(t0 + (uint32_t)k * 256u + (uint32_t)tid, xr_j);
+      }
     }
   }
   __syncthreads(); // (LDS is reused by this workgroup's next group)
@@ -502,7 +565,7 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
       if (keep[k]) prep_store(a.prep + tri_off + t, P[k], bb[k]);
       chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
     }
-    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, s_cnt, s_off, s_fill, s_misc);
+    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, P, s_cnt, s_off, s_fill, s_misc);
   }
   if (STATS) {
     if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
@@ -535,7 +598,7 @@ __global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
       keep[k] = bb[k].sx <= bb[k].ex; // (the empty box of a culled triangle: sx > ex)
       chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
     }
-    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, s_cnt, s_off, s_fill, s_misc);
+    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, nullptr, s_cnt, s_off, s_fill, s_misc);
   }
 }
 
@@ -1282,11 +1345,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     uint32_t nV, nS, word; // items of the two kinds; packed x0 | y0 << 5 | v << 10 | nseg << 16 | ws << 19
     float zmin;            // nearest vertex depth
   };
-  auto geometry = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, bool valid) {
+  auto geometry = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, float s_area, bool valid) {
     // r0 = ax ay z0 bx | r1 = by z1 cx cy | r2 = z2 bbx bby -
     const uint32_t bbx = f2u(r2.y), bby = f2u(r2.z);
     const int bsx = (int16_t)(bbx & 0xffff), bsy = (int16_t)(bbx >> 16), bex = (int16_t)(bby & 0xffff), bey = (int16_t)(bby >> 16);
-    const int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
+    int x0 = max(bsx, tx0) - tx0, x1 = min(bex, tx1) - tx0, y0 = max(bsy, ty0) - ty0, y1 = min(bey, ty1) - ty0;
+    // the rectangle that is walked: bounding box ∩ tile, tightened to the triangle (see tight_margin): the triangle's x-extent
+    // inside the rectangle's rows, then its y-extent inside the remaining columns.  About half of the pixel tests of a large
+    // triangle and 30 % of a small one's go away (the integer box starts at trunc(min), a column / row before the first pixel
+    // centre that can be inside; a large triangle's rectangle in a tile is mostly outside it).
+    {
+      const float ax = r0.x, ay = r0.y, bx = r0.w, by = r1.x, cx = r1.z, cy = r1.w;
+      float m, mn, mx;
+      if (tight_margin(ax, ay, bx, by, cx, cy, s_area, m)) {
+        int X0 = tx0 + x0, X1 = tx0 + x1, Y0 = ty0 + y0, Y1 = ty0 + y1;
+        slab_extent(ax, ay, bx, by, cx, cy, (float)Y0 - m, (float)Y1 + m, mn, mx);
+        clip_range(X0, X1, mn, mx, m);
+        slab_extent(ay, ax, by, bx, cy, cx, (float)X0 - m, (float)X1 + m, mn, mx);
+        clip_range(Y0, Y1, mn, mx, m);
+        x0 = X0 - tx0, x1 = X1 - tx0, y0 = Y0 - ty0, y1 = Y1 - ty0;
+      }
+    }
     const int vend = (flags & SRZ_UNIFIED) ? bex + 1 : bsx + ((bex - bsx + 1) & ~7);
     const int v = min(max(vend - tx0, x0), x1 + 1);
     Geo g;
@@ -1336,7 +1415,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
       if (base + 128 < cnt) i_nxt = list[min(base + 128u + (uint32_t)lane, cnt - 1u)];
     }
-    const Geo G = geometry(r0, r1, r2, valid);
+    const Geo G = geometry(r0, r1, r2, rec_s_area, valid);
     const uint32_t geom = G.word;
     uint32_t group = 0, n_groups = 1, znear = 0, znear_s = 0; // nearest possible depth of a V / S fragment, as keys (0: unknown → kept)
     if ((uint32_t)rl_i((int)wave_scan_add(8u * G.nV + G.nS), 63) > 4u * TILE * TILE) { // > 4 pixel tests per pixel of the tile
