@@ -1321,12 +1321,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   // (the first 64 indices of the tile's list are loaded under the tile init)
   const uint32_t i_first = as_const(a.pool)[off + min((uint32_t)lane, cnt - 1u)];
   // ---- phase A: tile init (fused clear → +inf, else the in/out z plane) with the incoming-depth tie-break ----------
-  for (int i = (int)threadIdx.x; i < TILE * TILE; i += 64 * WAVES) {
-    const int ly = i >> 5, lx = i & 31;
-    float z = __builtin_inff();
-    if (!fused && tx0 + lx <= tx1 && ty0 + ly <= ty1) z = out0[(size_t)ly * W + tx0 + lx];
-    const uint32_t zk = (z == z) ? zkey_of(z) : 0u; // a NaN already in the buffer: only the ordered algorithm knows
-    s_key[ly * KEY_STRIDE + lx] = ((unsigned long long)zk << 32) | TB_NONE;
+  if (fused) { // (wave-uniform) straight stores of one constant: nothing here waits for the index load above
+    const unsigned long long k_inf = ((unsigned long long)zkey_of(__builtin_inff()) << 32) | TB_NONE;
+    unsigned long long *kp = &s_key[((int)threadIdx.x >> 5) * KEY_STRIDE + ((int)threadIdx.x & 31)];
+#pragma unroll
+    for (int it = 0; it < TILE * TILE / (64 * WAVES); ++it) kp[it * (2 * WAVES * KEY_STRIDE)] = k_inf; // (one address, 16 offsets)
+  } else {
+    for (int i = (int)threadIdx.x; i < TILE * TILE; i += 64 * WAVES) {
+      const int ly = i >> 5, lx = i & 31;
+      float z = __builtin_inff();
+      if (tx0 + lx <= tx1 && ty0 + ly <= ty1) z = out0[(size_t)ly * W + tx0 + lx];
+      const uint32_t zk = (z == z) ? zkey_of(z) : 0u; // a NaN already in the buffer: only the ordered algorithm knows
+      s_key[ly * KEY_STRIDE + lx] = ((unsigned long long)zk << 32) | TB_NONE;
+    }
   }
   // the pad key of every row is scratch: 64 dword marks, mark r in row r / 2
   // (plain LDS accesses: the mark a triangle writes may be the one this lane reads, so the compiler keeps their order;
