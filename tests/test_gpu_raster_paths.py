@@ -199,3 +199,66 @@ def test_band_with_more_pairs_than_the_lds_stage(ctx, orc):
     t["pos"][:, :, 2] = rng.uniform(5, 50, (n, 1))
     t["nrm"][:] = [0, 0, -1]
     both_paths(ctx, orc, lambda extra: frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR | extra), what="stage overflow")
+
+
+def adversarial_tris(seed, n, w, h):
+    """the shapes the tightened rectangles (k_raster's slab clips, bucket_group's band clips) must stay conservative for:
+    needles, slivers, huge and far-off-screen vertices (past the 2^20 guard too), sub-pixel triangles around pixel centres,
+    edges exactly through pixel centres and along tile borders, ordinary large triangles — in both windings"""
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, abi.TRI_DTYPE)
+    kind = rng.integers(0, 7, n)
+    c = rng.uniform([0, 0], [w, h], (n, 2))
+    ang = rng.uniform(0, 2 * np.pi, n)
+    d = np.stack([np.cos(ang), np.sin(ang)], 1)
+    nrm = np.stack([-d[:, 1], d[:, 0]], 1)
+    xy = np.zeros((n, 3, 2))
+    L = rng.uniform(100, 600, n)[:, None]
+    # 0 needles: a very short base, the apex far away
+    k = kind == 0
+    base = (10.0 ** rng.uniform(-3, 0, n))[:, None]
+    xy[k] = np.stack([c, c + nrm * base, c + d * L], 1)[k]
+    # 1 slivers: a long edge, a height of 1e-4 .. 0.5 pixels
+    k = kind == 1
+    hgt = (10.0 ** rng.uniform(-4, -0.3, n))[:, None]
+    xy[k] = np.stack([c, c + d * L, c + d * L * rng.uniform(0, 1, (n, 1)) + nrm * hgt], 1)[k]
+    # 2 huge: vertices 1e3 .. 1e6 pixels out;  3 past the guard: one vertex 2e6 .. 1e8 out
+    k = kind == 2
+    xy[k] = (c[:, None, :] + rng.normal(size=(n, 3, 2)) * (10.0 ** rng.uniform(3, 6, (n, 1, 1))))[k]
+    k = kind == 3
+    far = c[:, None, :] + rng.normal(size=(n, 3, 2)) * 300.0
+    far[:, 0] += d * (10.0 ** rng.uniform(6.3, 8, n))[:, None]
+    xy[k] = far[k]
+    # 4 sub-pixel triangles around pixel centres
+    k = kind == 4
+    xy[k] = (np.round(c)[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * (10.0 ** rng.uniform(-3, 0, (n, 1, 1))))[k]
+    # 5 integer / half-integer / tile-border vertices: edges through pixel centres, exact zeros of the edge functions
+    k = kind == 5
+    grid = rng.choice([1.0, 0.5, 32.0], (n, 1, 1))
+    xy[k] = (np.round((c[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * rng.uniform(2, 200, (n, 1, 1))) / grid) * grid)[k]
+    # 6 ordinary large triangles
+    k = kind == 6
+    xy[k] = (c[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * rng.uniform(30, 400, (n, 1, 1)))[k]
+    flip = rng.random(n) < 0.5
+    xy[flip] = xy[flip][:, ::-1]
+    t["pos"][:, :, :2] = xy
+    # (the screen-filling kinds lie behind the others, so that every small shape decides pixels of the final image)
+    t["pos"][:, :, 2] = np.where((kind == 2) | (kind == 3), rng.uniform(60, 80, n), rng.uniform(2, 60, n))[:, None] + rng.uniform(-1, 1, (n, 3))
+    nn = rng.normal(size=(n, 3, 3))
+    t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+    t["uv"] = rng.uniform(0, 1, (n, 3, 2))
+    return t
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tight_rectangles_stay_conservative_on_adversarial_shapes(ctx, orc, seed):
+    """k_raster walks, and k_bin lists, the rectangle of a triangle tightened by slab clips with a margin (tight_margin): every
+    pixel the reference's bounding-box walk would set must still be tested.  Against the oracle (plain bounding boxes) and against
+    the ordered rasteriser (plain bounding boxes too), on shapes built to break a careless clip."""
+    w, h = (640, 416) if seed % 2 == 0 else (333, 517)
+    t = adversarial_tris(40 + seed, 800, w, h)
+    sh = [abi.SHADER_NORMAL, abi.SHADER_PHONG, abi.SHADER_TEXTURE][seed % 3]
+    tex = scenes.TEX_SPOT if sh == abi.SHADER_TEXTURE else -1
+    fl = abi.FUSED_CLEAR | (abi.UNIFIED if seed == 5 else 0)
+    lights = [((100.0, 100.0, -50.0), (300.0, 300.0, 300.0)), ((400.0, 50.0, 80.0), (200.0, 200.0, 200.0))]
+    both_paths(ctx, orc, lambda extra: frame(t, w, h, shader=sh, tex=tex, lights=lights, flags=fl | extra), what=f"adversarial shapes {seed}")
