@@ -390,15 +390,20 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
     achieved = case.algo_bytes / pipeline_s / 1e9 if pipeline_s > 0 else 0.0
     pm = pmc_counters(case.name, case.n_frames, case.scope) if case.world == 1 else None
     # VALU issue beside the HBM fraction (a kernel can sit far below the HBM roofline because it is bound by instruction issue):
-    # wave-instructions per step / what the 1024 SIMDs issue in the step's device time at one wave64 VALU instruction per 4
-    # cycles — one wave's own issue rate; a SIMD-32 that interleaves two or more waves retires one every 2 cycles, so 0.5 by
-    # this measure is a saturated pipe only for code without ILP between waves, and 1.0 would be every SIMD issuing back to back
+    # wave-instructions per step x 2 cycles / the SIMD-cycles of the step's device time.  A CDNA4 SIMD is 32 lanes wide: with two
+    # or more resident waves it retires one plain wave64 VALU instruction per 2 cycles (measured, tools/cpp/valu_rate_probe.hip:
+    # v_fma_f32 2.5 cycles at the nominal 2.4 GHz, i.e. 2 at the clock the chip sustains under that load; one wave alone 5.6;
+    # v_mul_f64 and v_pk_fma_f32 4.2-4.5, v_rcp_f32 8.2) — so this is a LOWER bound of the pipe's occupancy;
+    # valu_pipe_frac_est prices binary64 arithmetic at 4 and transcendentals at 8 cycles from the instruction-class counters
+    # (packed f32 instructions, 4 cycles, are not counted apart: still a lower bound)
     valu = None
     if pm and pipeline_s > 0:
+        simd_cycles = N_SIMD * SCLK_HZ * pipeline_s
         valu = {"valu_wave_insts_per_step": pm["valu_wave_insts_per_step"],
-                "valu_frac": pm["valu_wave_insts_per_step"] / (N_SIMD * SCLK_HZ * pipeline_s / 4.0),
+                "valu_frac": pm["valu_wave_insts_per_step"] * 2.0 / simd_cycles,
+                "valu_pipe_frac_est": (pm["valu_pipe_cycles_per_step"] / simd_cycles) if pm.get("valu_pipe_cycles_per_step") else None,
                 "valu_per_64_visible_px": pm["valu_wave_insts_per_step"] / max(1.0, vis_total / 64.0),
-                "definition": "SQ_INSTS_VALU per step / (1024 SIMDs x 2.4 GHz x launch_ms / 4)",
+                "definition": "SQ_INSTS_VALU per step x 2 cycles / (1024 SIMDs x 2.4 GHz x launch_ms)",
                 "source": f"profiles/{pm['from']} (rocprofv3 --pmc pass of this workload, --lanes 1; not measured in this run)"}
     return {
         "workload": case.name, "scope": case.scope, "lanes": kt.get("lanes", 1), "width": fs.width, "height": fs.height,

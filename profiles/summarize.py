@@ -81,17 +81,30 @@ for jf in sorted(glob.glob(os.path.join(src, "*.traced.json"))):
         shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv" if w == head else f"{tag}_{w}_kernel_stats.csv"))
         us = kernel_us(stats)
         fetch, write, sq = pmc(f"{w}/pmc_fetch"), pmc(f"{w}/pmc_write"), pmc(f"{w}/pmc_sq")
+        try:
+            mix, occ = pmc(f"{w}/pmc_mix"), pmc(f"{w}/pmc_occ")
+        except AssertionError:
+            mix, occ = {}, {}
     except (AssertionError, ValueError, IndexError) as e:
         print("skipped", w, e)
         continue
-    per_kernel, tot_f, tot_w, tot_valu = {}, 0.0, 0.0, 0.0
+    per_kernel, tot_f, tot_w, tot_valu, tot_pipe = {}, 0.0, 0.0, 0.0, 0.0
     for k in KERNELS:
         if k not in us and k not in sq:
             continue
         f = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024
         wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
         tot_f, tot_w, tot_valu = tot_f + f, tot_w + wr, tot_valu + sq.get(k, {}).get("SQ_INSTS_VALU", 0.0)
-        per_kernel[k] = {"avg_us": us.get(k), "fetch_bytes_raw": f, "write_bytes": wr, **sq.get(k, {})}
+        # VALU pipe cycles, a lower bound: 2 per wave-instruction, 2 more for binary64 arithmetic, 6 more for a transcendental
+        # (tools/cpp/valu_rate_probe.hip; packed f32 instructions also take 4 but have no counter of their own)
+        mk = mix.get(k, {})
+        f64 = sum(mk.get(c, 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+        pipe = 2.0 * sq.get(k, {}).get("SQ_INSTS_VALU", 0.0) + 2.0 * f64 + 6.0 * (mk.get("SQ_INSTS_VALU_TRANS_F32", 0.0) + mk.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+        tot_pipe += pipe if mk else 0.0
+        per_kernel[k] = {"avg_us": us.get(k), "fetch_bytes_raw": f, "write_bytes": wr, **sq.get(k, {}), **mk,
+                         "valu_pipe_cycles_lower_bound": pipe if mk else None,
+                         "valu_pipe_frac_of_kernel_time": (pipe / (1024 * 2.4e9 * us[k] * 1e-6)) if mk and us.get(k) else None,
+                         "resident_waves_per_simd": occ.get(k, {}).get("MeanOccupancyPerCU")}
     algo = line["roofline"]["algorithmic_bytes_per_launch"]
     frames = line["config"]["frames_per_step"]
     out["workloads"][w] = {"frames_per_step": frames, "kernels": per_kernel,
@@ -103,6 +116,7 @@ for jf in sorted(glob.glob(os.path.join(src, "*.traced.json"))):
                            "valu_wave_insts_per_step": tot_valu,
                            "valu_per_64_visible_px": tot_valu / max(1.0, line["visible_pixels_per_frame"] * frames / 64.0)}
     counters[w] = {"frames_per_step": frames, "hbm_bytes_per_step": tot_w + 2 * tot_f, "valu_wave_insts_per_step": tot_valu,
+                   "valu_pipe_cycles_per_step": tot_pipe or None,
                    "from": f"{tag}_pmc.json"}
     print(f"{w:28s} pipeline {out['workloads'][w]['pipeline_us_sum']:8.1f} us  traffic/algorithmic {(tot_w + 2 * tot_f) / algo:.3f}  "
           f"VALU {tot_valu / 1e6:7.1f} M  per 64 visible px {out['workloads'][w]['valu_per_64_visible_px']:.0f}  "
