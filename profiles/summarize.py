@@ -104,7 +104,7 @@ for jf in sorted(glob.glob(os.path.join(src, "*.traced.json"))):
         per_kernel[k] = {"avg_us": us.get(k), "fetch_bytes_raw": f, "write_bytes": wr, **sq.get(k, {}), **mk,
                          "valu_pipe_cycles_lower_bound": pipe if mk else None,
                          "valu_pipe_frac_of_kernel_time": (pipe / (1024 * 2.4e9 * us[k] * 1e-6)) if mk and us.get(k) else None,
-                         "resident_waves_per_simd": occ.get(k, {}).get("MeanOccupancyPerCU")}
+                         "resident_waves_per_cu": occ.get(k, {}).get("MeanOccupancyPerCU")}  # (of 4 SIMDs; k_clear: 64 workgroups of 4 waves = 1.0)
     algo = line["roofline"]["algorithmic_bytes_per_launch"]
     frames = line["config"]["frames_per_step"]
     out["workloads"][w] = {"frames_per_step": frames, "kernels": per_kernel,
