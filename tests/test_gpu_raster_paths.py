@@ -250,7 +250,7 @@ def adversarial_tris(seed, n, w, h):
     return t
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SRZ_ADVERSARIAL_SEEDS", "6"))))
 def test_tight_rectangles_stay_conservative_on_adversarial_shapes(ctx, orc, seed):
     """k_raster walks, and k_bin lists, the rectangle of a triangle tightened by slab clips with a margin (tight_margin): every
     pixel the reference's bounding-box walk would set must still be tested.  Against the oracle (plain bounding boxes) and against
