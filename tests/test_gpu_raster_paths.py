@@ -262,3 +262,23 @@ def test_tight_rectangles_stay_conservative_on_adversarial_shapes(ctx, orc, seed
     fl = abi.FUSED_CLEAR | (abi.UNIFIED if seed == 5 else 0)
     lights = [((100.0, 100.0, -50.0), (300.0, 300.0, 300.0)), ((400.0, 50.0, 80.0), (200.0, 200.0, 200.0))]
     both_paths(ctx, orc, lambda extra: frame(t, w, h, shader=sh, tex=tex, lights=lights, flags=fl | extra), what=f"adversarial shapes {seed}")
+
+
+def test_tight_rectangles_in_the_throughput_build(ctx, orc):
+    """the same shapes as a BATCH: 18 frames of 20 x 13 tiles = 4680 tiles — above the 4096 of the four-waves-per-tile build, so
+    this is k_raster<1>, k_clear on its side stream and the frameset path; every frame against the oracle"""
+    w, h = 640, 416
+    lights = [((100.0, 100.0, -50.0), (300.0, 300.0, 300.0)), ((400.0, 50.0, 80.0), (200.0, 200.0, 200.0))]
+    shaders = [abi.SHADER_NORMAL, abi.SHADER_PHONG, abi.SHADER_TEXTURE]
+    frames = [frame(adversarial_tris(900 + i, 350, w, h), w, h, shader=shaders[i % 3], tex=scenes.TEX_SPOT if i % 3 == 2 else -1,
+                    lights=lights, flags=abi.FUSED_CLEAR) for i in range(18)]
+    fs = ctx.frameset(frames)
+    out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+    for _ in range(2):  # (the second render runs with the pool sized by the first)
+        fs.render(out.data_ptr(), fs.out_bytes, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i, f in enumerate(frames):
+        rc, ref, _ = orc.draw(f)
+        assert rc == 0
+        same(got[i], ref, f"batch frame {i}")
