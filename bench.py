@@ -8,15 +8,21 @@ variation), inputs (post-MVP triangle streams, lights, texture) already resident
 framebuffer layout (z + 3 planar float colour planes per frame) in HBM.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...          (N > 1 without a launcher: bench.py starts the N ranks itself — launch_ranks below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N = 1 also measures, after the headline config and outside its timed region, the other GPU configs of BASELINE.json
 (configs[2..4], whole frames on one GPU) and configs[1] at scope "draw" (vertex stage timed too): `configs` in the JSON.
 
 N > 1: one process per GPU; every frame's 32-row bands are dealt round-robin to the ranks (srz_set_shard), each rank
-renders its bands of F*N frames (per-GPU pixel work fixed → weak scaling), and the exchange north_star names — an RCCL
-all-gather over xGMI behind the C ABI (srz_frameset_allgather) + one HIP de-interleave pass — reassembles every full
-framebuffer on every rank.  The exchange of step k runs on its own stream while step k+1 renders (double-buffered).
+renders its bands of F*N frames (per-GPU pixel work fixed → weak scaling), and the exchange north_star names — ONE in-place
+RCCL all-gather over xGMI behind the C ABI (srz_frameset_allgather_inplace) — reassembles every full framebuffer on every
+rank.  The exchange of step k runs on its own stream while step k+1 renders (double-buffered).
+WHAT is exchanged at N > 1 (decided and stated here): the headline (`value`) exchanges `bgr8` — the reference's
+final framebuffer IS the 8-bit image: display() merges the planes into m_frameBuffer and converts it to CV_8UC3 in place
+(src/Render.cpp:61-62) — i.e. every rank resolves its bands on the device (k_resolve8) and all-gathers 3 B/px; the same
+run then times the exchange of the four float planes (16 B/px: z + the three m_channels) and reports it beside the headline in
+`multi_gpu.planes`, with DESIGN.md §6's prediction for both in `multi_gpu.predicted`.
 
 Prints ONE JSON line (rank 0).  PyTorch is only plumbing here (device buffers, streams, the rendezvous).
 """
@@ -40,6 +46,95 @@ EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 12
                # counts / exponents), p = 7.5 (the generic build), the BUMP shader
                ("spot_texture_1024_3lights", 256, 10), ("spot_texture_1024_p32", 256, 10), ("spot_texture_1024_p7.5", 256, 10),
                ("spot_bump_1024", 256, 10)]
+
+
+# workloads whose summary goes into roofline.per_config (the part of the line the driver's parser keeps): BASELINE configs 3 / 4 / 5,
+# the scene of the reference's one published figure, configs[1] at scope draw, the exponent variant the generic build used to serve
+PER_CONFIG = ("spot_bunny_phong_1080p", "spot_x16_texture_2048", "spot_x8_overdraw_4096", "readme_spot_crate_1024", "spot_texture_1024_p7.5")
+HBM_BYTES = 288e9  # per MI355X
+
+
+def kernel_source_hash():
+    """sha256 over the device sources the PMC passes profiled (csrc/*.hip + csrc/srz_device.h + include/srz.h), first 16 hex
+    digits: profiles/summarize.py stores it in profiles/pmc_counters.json, and a bench line of OTHER sources reports
+    traffic: null + traffic_stale instead of another code version's counters"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(REPO, "software-rasterizer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + [os.path.join(base, "srz_device.h"), os.path.join(REPO, "include", "srz.h")]):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (the same command the driver
+    uses: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>), relay rank 0's JSON line as this
+    process's own last line of stdout and return the children's exit status.  Called BEFORE this process imports torch or
+    touches HIP (a process that has initialised the GPU must not start others by exec, and must not hold the GPU while the
+    ranks need it); the children are a process group of their own, killed as a group if they outlive the time limit."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, SRZ_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this host driver)
+    limit = float(os.environ.get("SRZ_BENCH_LAUNCH_TIMEOUT", "1500"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, start_new_session=True)
+    line = None
+
+    def on_alarm(signum, frame):
+        raise TimeoutError
+    signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(int(limit))
+    try:
+        for out in p.stdout:
+            if out.startswith('{"metric"'):
+                line = out.strip()
+            else:
+                sys.stderr.write(out)
+        rc = p.wait()
+    except TimeoutError:
+        os.killpg(p.pid, signal.SIGKILL)  # (exactly the group started above)
+        p.wait()
+        sys.stderr.write(f"bench.py: the {n_ranks} ranks did not finish within {limit:.0f} s; killed\n")
+        return 124
+    finally:
+        signal.alarm(0)
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+        return 1
+    return rc
+
+
+def readme_loop():
+    """The reference's own published protocol (README.md:619-642: 1024x1024, spot + crate scene, 100 warm-up + 1000 frames, clear()
+    per frame, the angle rotated every frame, std::chrono around draw(); ONE frame in flight — latency, not throughput) through
+    the C++ API: software-rasterizer_amd/build/loop_bench (tools/cpp/loop_bench.cpp, built by __graft_entry__.build()), run as a
+    child process BEFORE this process touches the GPU.  → its JSON record, or {"error": ...}"""
+    import subprocess
+    exe = os.path.join(REPO, "software-rasterizer_amd", "build", "loop_bench")
+    if not os.path.exists(exe):  # (normally built by __graft_entry__.build(); the GPU box has the same toolchain)
+        subprocess.run(["make", "-s", "-C", os.path.join(REPO, "software-rasterizer_amd"), "build/loop_bench"], capture_output=True)
+    if not os.path.exists(exe):
+        return {"scope": "readme_loop", "error": f"{exe} not built (run __graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe, REPO, "1000", "readme"], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"scope": "readme_loop", "error": f"loop_bench exited {r.returncode}: {r.stderr[-300:]}"}
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+        return {"scope": "readme_loop", "error": repr(e)}
+    rec.update({"workload": "readme_spot_crate_1024", "scope": "readme_loop", "width": 1024, "height": 1024, "warmup_frames": 100,
+                "protocol": "README.md:619-642 of the reference: one frame in flight, clear() + matrices + draw() per frame"})
+    return rec
 
 
 def host_cpu_info():
@@ -370,17 +465,27 @@ def pmc_counters(workload, frames_per_step, scope):
     """HBM bytes and VALU wave-instructions per step of this workload from profiles/pmc_counters.json — the rocprofv3 --pmc passes
     of the same bench.py command with --lanes 1 (profiles/collect.sh; the counters are per dispatch, i.e. per step of a
     one-stream run: the bytes and instructions of a step do not depend on how its launches are spread over streams).  NOT
-    measured in this run: a profile of another code version describes that version."""
+    measured in this run: a profile of another code version describes that version — the file carries the hash of the kernel
+    sources it profiled (kernel_source_hash), and counters of other sources are not reported (→ None; pmc_stale() says why)."""
     global _PMC
     if _PMC is None:
         try:
             _PMC = json.load(open(os.path.join(REPO, "profiles", "pmc_counters.json")))
         except Exception:  # noqa: BLE001
             _PMC = {}
+    if pmc_stale():
+        return None
     t = _PMC.get(workload)
-    if not t or t.get("frames_per_step") != frames_per_step or scope != "raster":
+    if not isinstance(t, dict) or t.get("frames_per_step") != frames_per_step or scope != "raster":
         return None
     return t
+
+
+def pmc_stale():
+    """True when profiles/pmc_counters.json was collected from other kernel sources than the ones in this tree"""
+    if _PMC is None:
+        pmc_counters("", 0, "")
+    return bool(_PMC) and _PMC.get("_kernel_source_hash") != kernel_source_hash()
 
 
 def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
@@ -415,13 +520,53 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
         "fragments_per_frame": frag_total / fs.n_frames, "visible_pixels_per_frame": vis_total / fs.n_frames,
         "valu": valu,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pm["hbm_bytes_per_step"] if pm else None,
+                     "traffic": pm["hbm_bytes_per_step"] if pm else None, "traffic_stale": (pmc_stale() and case.world == 1) or None,
                      "traffic_over_algorithmic": pm["hbm_bytes_per_step"] / case.algo_bytes if pm else None,
                      "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
                      "lanes": kt.get("lanes", 1), "lane_launch_ms": kt.get("lane_launch_ms"),
                      "one_stream": {"ms_per_step": kt.get("one_stream_ms_per_step"), "launch_ms": kt.get("split_total_ms"),
                                     "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]}},
     }
+
+
+def per_config_summary(rec):
+    """the compact per-workload record of roofline.per_config"""
+    if "error" in rec:
+        return {"error": rec["error"]}
+    if rec.get("scope") == "readme_loop":
+        return {"scope": "readme_loop", "draw_complete_ms_p10_median_p90": [rec["draw_complete_ms"][k] for k in ("p10", "median", "p90")],
+                "draw_submit_ms_median": rec["draw_submit_ms"]["median"], "display_ms_median": rec["display_ms"]["median"],
+                "frames": rec["frames"], "reference_published_draw_ms_median": 17.06}
+    r, v = rec["roofline"], rec.get("valu") or {}
+    return {"scope": rec["scope"], "frames_per_step": rec["frames_per_step"], "lanes": rec["lanes"], "frames_per_sec": rec["frames_per_sec"],
+            "ms_per_step": rec["ms_per_step"], "frac": r["frac"], "traffic_over_algorithmic": r["traffic_over_algorithmic"],
+            "valu_pipe_frac_est": v.get("valu_pipe_frac_est"),
+            "one_stream_us": {"setup_bin": r["one_stream"]["k_setup_bin_ms"] * 1e3, "raster": r["one_stream"]["k_raster_ms"] * 1e3,
+                              "shade": r["one_stream"]["k_shade_ms"] * 1e3}}
+
+
+def multi_gpu_budget(args, world, wl_name):
+    """HBM the N > 1 loop allocates per rank, checked BEFORE anything is allocated (the in-place exchange keeps 2 gathered
+    buffers of world x shard each; the headline's 8-bit ones and the float planes' are not alive together)"""
+    from srz import parallel, scenes
+    wl = scenes.WORKLOADS[wl_name]()
+    lay = parallel.shard_layout(wl.height, 0, world)
+    n_frames = args.frames * world
+    shard_planes = n_frames * 16 * lay["local_rows"] * wl.width
+    shard_bgr8 = n_frames * 3 * lay["local_rows"] * wl.width
+    planes_case = 2 * shard_planes                                   # Case.out (n_out = 2): the rank's own float planes
+    peak = planes_case + max(2 * world * shard_bgr8, 2 * world * shard_planes)
+    inputs = n_frames * (wl.frame(0).n_tris * (96 + 48 + 8 + 2 + 40) + 8 * lay["local_rows"] * wl.width)  # streams, PrepTri, boxes, entries, lists
+    return {"frames_per_step": n_frames, "shard_bytes_planes": shard_planes, "shard_bytes_bgr8": shard_bgr8,
+            "gathered_buffers_bytes_planes": 2 * world * shard_planes, "gathered_buffers_bytes_bgr8": 2 * world * shard_bgr8,
+            "peak_bytes_estimate": peak + inputs, "hbm_bytes": HBM_BYTES}
+
+
+def predicted_exchange(shard_bytes, n_frames_total):
+    """every rank sends its shard once to each of the N - 1 peers over that peer's own xGMI link, so bytes per link
+    per step = shard bytes whatever N, and a step cannot be faster than that (render hidden under the exchange)"""
+    ms = shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+    return {"exchange_ms_at_xgmi_peak": ms, "frames_per_sec_if_exchange_bound": n_frames_total / (ms * 1e-3)}
 
 
 def main():
@@ -436,9 +581,10 @@ def main():
     ap.add_argument("--scope", choices=["raster", "draw"], default="raster",
                     help="raster: post-MVP triangle streams resident in HBM (BASELINE's hot path); "
                          "draw: meshes + per-frame matrices resident, the vertex stage (k_vertex) is timed too")
-    ap.add_argument("--exchange", choices=["planes", "bgr8"], default="planes",
-                    help="N>1 only. planes: all-gather the 4 float planes (16 B/px, the reference's framebuffer); "
-                         "bgr8: resolve to 8-bit on the device first and all-gather display()'s image (3 B/px)")
+    ap.add_argument("--exchange", choices=["bgr8", "planes", "both"], default="both",
+                    help="N>1 only. bgr8: resolve to 8-bit on the device and all-gather display()'s image, the reference's final "
+                         "m_frameBuffer (3 B/px) — the headline; planes: all-gather the 4 float planes (16 B/px: z + m_channels); "
+                         "both: the headline exchanges bgr8 and a second, shorter pass times planes (multi_gpu.planes)")
     ap.add_argument("--exchange-layout", choices=["shards", "rows"], default="shards",
                     help="N>1 only. shards: render into the rank's slot of the gathered buffer, ONE in-place all-gather, no second "
                          "pass (frames stay in rank-major shard order); rows: all-gather + a HIP de-interleave pass (row-major frames)")
@@ -447,42 +593,55 @@ def main():
                          "(srz.parallel.LaneRenderer: consecutive steps overlap at their edges); 1 = one frameset on one "
                          "stream; 0 = two lanes for steps of >= 64 frames, else one")
     ap.add_argument("--no-overlap", action="store_true", help="N>1 only: render and exchange back to back on one stream")
-    ap.add_argument("--no-extras", action="store_true", help="N=1: skip the other BASELINE configs / scope draw")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: skip the other BASELINE configs / scope draw / the README loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import srz
-    from srz import abi, parallel
-
+    # ---- no launcher around us: start the ranks ourselves, BEFORE torch / HIP are touched in this process ----------------------
+    # (SRZ_BENCH_FORCE_LAUNCHER=1: take this path at N = 1 too — one child that runs the N > 1 code at world 1: tests)
+    force = os.environ.get("SRZ_BENCH_FORCE_LAUNCHER") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force):
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run with N ranks")
-        args.gpus = world
+        args.gpus = world  # (the launcher decides)
+    multi_path = world > 1 or (force and os.environ.get("SRZ_BENCH_LAUNCHED") == "1")
+
+    # the reference's published protocol through the C++ API: a child process, before this one initialises the GPU
+    loop_rec = readme_loop() if (world == 1 and not multi_path and not args.no_extras) else None
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    import srz
+    from srz import abi, parallel  # noqa: F401
+
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        budget = multi_gpu_budget(args, world, args.workload)
+        free_b, total_b = torch.cuda.mem_get_info()
+        if budget["peak_bytes_estimate"] > 0.85 * total_b:
+            sys.exit(f"bench.py: --frames {args.frames} x {world} ranks needs ~{budget['peak_bytes_estimate'] / 1e9:.0f} GB per GPU "
+                     f"(2 x world x shard gathered buffers), the device has {total_b / 1e9:.0f} GB: lower --frames")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi_path:
             dist.barrier()
             torch.cuda.synchronize()
 
     ctx = srz.Context(local_rank, rank, world)
-    comm, comm_note = (None, None) if world == 1 else make_comm(ctx, dist, torch, rank, world)
+    comm, comm_note = (None, None) if not multi_path else make_comm(ctx, dist, torch, rank, world)
 
-    case = Case(ctx, torch, args.workload, args.frames, args.scope, world, n_out=2 if world > 1 else 1)
+    case = Case(ctx, torch, args.workload, args.frames, args.scope, world, n_out=2 if multi_path else 1)
     fs, stats = case.fs, case.stats
-    if world > 1:
+    if multi_path:
         st = torch.tensor([stats["fragments"], stats["visible"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(st)
         frag_total, vis_total = int(st[0]), int(st[1])
@@ -490,24 +649,43 @@ def main():
         frag_total, vis_total = stats["fragments"], stats["visible"]
 
     multi = None
-    if world == 1:
+    if not multi_path:
         dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes)
     else:
-        dt, kt, per_step, multi = time_multi_gpu(case, comm, dist if world > 1 else None, args.steps, args.warmup, fence, args.exchange,
+        head_x = "planes" if args.exchange == "planes" else "bgr8"
+        dt, kt, per_step, multi = time_multi_gpu(case, comm, dist, args.steps, args.warmup, fence, head_x,
                                                  args.no_overlap, args.exchange_layout, rank)
         multi.pop("last_full")
+        multi["headline_exchange"] = head_x
+        multi["why"] = ("bgr8 = display()'s m_frameBuffer after convertTo(CV_8UC3) (src/Render.cpp:61-62 of the reference): the final "
+                        "framebuffer; planes = z + the three float m_channels (what draw() leaves)")
+        multi["budget"] = budget
+        multi["predicted"] = {"bgr8": predicted_exchange(budget["shard_bytes_bgr8"], case.n_frames),
+                              "planes": predicted_exchange(budget["shard_bytes_planes"], case.n_frames),
+                              "source": "DESIGN.md §6: shard bytes / 153 GB/s per xGMI link; render (≈ the N = 1 step) hidden under it"}
+        if args.exchange == "both":  # the float planes beside the headline: fewer steps (≈ 5x the bytes per step)
+            torch.cuda.empty_cache()
+            k2 = max(3, args.steps // 4)
+            dt2, kt2, _, m2 = time_multi_gpu(case, comm, dist, k2, min(args.warmup, 2), fence, "planes", args.no_overlap,
+                                             args.exchange_layout, rank)
+            m2.pop("last_full")
+            multi["planes"] = {"frames_per_sec": case.n_frames * k2 / dt2, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+                               "render_ms_per_step": m2["render_ms_per_step"], "exchange_alone_ms_per_step": m2["exchange_alone_ms_per_step"],
+                               "hidden_ms_per_step": m2["hidden_ms_per_step"], "bytes_sent_per_rank_per_step": m2["bytes_sent_per_rank_per_step"]}
         if comm_note:
             multi["fallback"] = comm_note
 
     res = None
     if rank == 0:
         rec = case_record(case, args.steps, dt, kt, per_step, frag_total, vis_total)
-        pm = pmc_counters(args.workload, case.n_frames, args.scope) if world == 1 else None
+        pm = pmc_counters(args.workload, case.n_frames, args.scope) if not multi_path else None
         traffic, traffic_src = (pm["hbm_bytes_per_step"], f"profiles/{pm['from']}") if pm else (None, None)
         roof = rec["roofline"]
         roof.update({"traffic": traffic,
                      "traffic_source": (f"{traffic_src}: FETCH_SIZE x2 + WRITE_SIZE of rocprofv3 --pmc passes of this command with --lanes 1 "
-                                        "(same bytes per step, kernels not overlapped), per step (not measured in this run)") if traffic else None,
+                                        "(same bytes per step, kernels not overlapped), per step (not measured in this run; "
+                                        "kernel sources' hash checked)") if traffic else None,
+                     "kernel_source_hash": kernel_source_hash(),
                      "frac_of_measured_copy_6290": roof["achieved"] / HBM_MEASURED_COPY_GBS,
                      "kernel": "hot path = k_setup + k_bin + k_raster (+ k_raster_slow) + k_shade in line, k_clear beside k_raster/k_shade "
                                "on a second stream (one launch each per lane per step)",
@@ -524,8 +702,8 @@ def main():
             "config": {"workload": args.workload, "width": fs.width, "height": fs.height,
                        "frames_per_step": case.n_frames, "frames_per_step_per_gpu": args.frames,
                        "triangles_per_frame": case.tris_per_frame, "lights": len(case.frames[0].lights), "scope": args.scope,
-                       "sharding": "whole frames on 1 GPU" if world == 1 else
-                       f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {args.exchange}, layout {args.exchange_layout} (timed)"},
+                       "sharding": "whole frames on 1 GPU" if not multi_path else
+                       f"32-row bands round-robin over {world} GPUs + RCCL all-gather of {multi['headline_exchange']}, layout {args.exchange_layout} (timed)"},
             "mfragments_per_sec": rec["mfragments_per_sec"], "fragments_per_frame": rec["fragments_per_frame"],
             "visible_pixels_per_frame": rec["visible_pixels_per_frame"],
             "ms_per_step_p10_median_p90": rec["ms_per_step_p10_median_p90"], "us_per_frame_median": rec["us_per_frame_median"],
@@ -538,12 +716,13 @@ def main():
     case.close()
 
     # ---- N = 1: the other GPU configs of BASELINE.json + configs[1] at scope draw, each outside the headline's timed region
-    if world == 1 and not args.no_extras:
+    if not multi_path and not args.no_extras:
         extras = []
         todo = [(w, f, s, "raster", args.lanes) for (w, f, s) in EXTRA_CASES if w != args.workload]
         todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster", args.lanes))
         # the headline workload once more the other way (one frameset on one stream / two lanes on two streams)
         todo.append((args.workload, args.frames, args.steps, args.scope, 2 if args.lanes == 1 else 1))
+        per_config = {}
         for (w, f, s, scope, n_lanes) in todo:
             try:
                 c = Case(ctx, torch, w, f, scope, 1)
@@ -552,14 +731,22 @@ def main():
                 c.close()
             except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
                 extras.append({"workload": w, "scope": scope, "error": str(e)})
+            if w in PER_CONFIG and scope == "raster":
+                per_config[w] = per_config_summary(extras[-1])
+            elif w == args.workload and scope == "draw":
+                per_config[w + ":draw"] = per_config_summary(extras[-1])
+        if loop_rec is not None:
+            extras.append(loop_rec)
+            per_config["readme_spot_crate_1024:readme_loop"] = per_config_summary(loop_rec)
         res["configs"] = extras
-    if world == 1 and not args.no_cpu_baseline:
+        res["roofline"]["per_config"] = per_config
+    if not multi_path and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_budget_s)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if comm is not None:
         comm.close()
-    if world > 1:
+    if multi_path:
         dist.destroy_process_group()
 
 

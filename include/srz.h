@@ -38,8 +38,9 @@ extern "C" {
  *   3  `stream` arguments: NULL = the ctx's own stream, SRZ_STREAM_NULL = HIP's null stream (was: NULL = null stream);
  *      srz_comm_*, srz_frameset_allgather / _deinterleave / _exchange_bytes, srz_kernel_time_samples
  *   4  srz_frameset_allgather_inplace, srz_frameset_gathered_row_offset, srz_frameset_read_gathered_frame
+ *   5  srz_set_option; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
  */
-#define SRZ_ABI_VERSION 4
+#define SRZ_ABI_VERSION 5
 
 /* error codes */
 #define SRZ_OK 0
@@ -160,6 +161,14 @@ int srz_create(srz_ctx **out, int device_id);
 void srz_destroy(srz_ctx *ctx);
 const char *srz_last_error(const srz_ctx *ctx); /* ctx may be NULL: last error of srz_create */
 
+/* Per-ctx switches (value 0 / 1), applied to framesets created AFTERWARDS:
+ *   SRZ_OPT_POOL_LAZY  1 = the first render of a set does NOT size the tile-list pool by its own demand (see srz_frameset_render:
+ *                      no host wait in the first render; bands whose lists do not fit take the ordered rasteriser until a later
+ *                      render has grown the pool).  Default 0, or 1 when the environment variable SRZ_POOL_LAZY is set — read
+ *                      ONCE, in srz_create. */
+#define SRZ_OPT_POOL_LAZY 1
+int srz_set_option(srz_ctx *ctx, int option, int value);
+
 /* Multi-GPU: this ctx owns the 32-row bands b with b % world == rank (local band b / world).
  * Default (0,1) = whole frame. Affects srz_frameset_* only. */
 int srz_set_shard(srz_ctx *ctx, int rank, int world);
@@ -193,7 +202,13 @@ int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_f
  * where local_rows = srz_frameset_local_rows() (= height for an unsharded ctx, else
  * bands_per_rank*32, zero-padded).  d_out is a DEVICE pointer (e.g. a torch tensor's data_ptr),
  * stream a hipStream_t (NULL = the ctx's own non-blocking stream; pass SRZ_STREAM_NULL for HIP's null stream:
- * work on the ctx's stream is NOT ordered against the null stream).  The call is asynchronous on that stream. */
+ * work on the ctx's stream is NOT ordered against the null stream).  The call is asynchronous on that stream — with ONE
+ * exception: the FIRST render of a set (per sub-batch of a very large one) waits on the host for the binning kernel's count
+ * of (triangle, tile) pairs (a device→host copy + hipStreamSynchronize(stream)), grows the tile-list pool if a band did not
+ * fit (hipDeviceSynchronize + hipMalloc) and bins again, so that a one-shot set is rendered by the fast path as a whole.  That
+ * first call therefore cannot be captured into a hipGraph and serialises with other streams; every later render of the set
+ * is asynchronous (the pool follows the previous renders' demand; growth — rare — is the one place they wait).
+ * srz_set_option(ctx, SRZ_OPT_POOL_LAZY, 1) before creating the set switches the blocking first render off. */
 #define SRZ_STREAM_NULL ((void *)(intptr_t)-1)
 int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out);
 /* Same, but the frames are given as meshes + matrices: every srz_frameset_render first runs the vertex stage on the

@@ -121,6 +121,10 @@ for jf in sorted(glob.glob(os.path.join(src, "*.traced.json"))):
     print(f"{w:28s} pipeline {out['workloads'][w]['pipeline_us_sum']:8.1f} us  traffic/algorithmic {(tot_w + 2 * tot_f) / algo:.3f}  "
           f"VALU {tot_valu / 1e6:7.1f} M  per 64 visible px {out['workloads'][w]['valu_per_64_visible_px']:.0f}  "
           + " ".join(f"{k[2:]}={v:.0f}" for k, v in us.items()))
+# the counters describe THESE kernel sources: bench.py reports them only for a tree whose sources hash the same
+sys.path.insert(0, os.path.dirname(here))
+import bench  # noqa: E402
+counters["_kernel_source_hash"] = out["kernel_source_hash"] = bench.kernel_source_hash()
 json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump(counters, open(counters_file, "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_plain.json"), os.path.join(here, f"{tag}_bench.json"))

@@ -59,6 +59,7 @@ struct srz_ctx {
   // default below), 32-bit owner ids even where 16 would do
   int env_sub_batch = 0;
   bool env_no_vis16 = false;
+  bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
   hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
@@ -107,7 +108,7 @@ struct srz_frameset {
   uint2 *d_tile_info = nullptr;
   uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr;
   uint32_t *d_redo_list = nullptr; // (its counter is d_slow_count[1])
-  uint32_t fast_mask = 0;   // bit NL (+ 8 with BUMP / DISPLACEMENT batches): some frame is shaded by that FAST build of k_shade (classify_frames)
+  uint32_t fast_mask = 0;   // bit NL (+ 8 with BUMP / DISPLACEMENT batches, + 16 with a non-integer exponent): some frame is shaded by that FAST build of k_shade (classify_frames)
   bool any_generic = true;  // some frame needs the generic build
   uint32_t *d_vis = nullptr, *d_worklist = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr;
   uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
@@ -166,22 +167,25 @@ void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &
   local_rows = world == 1 ? (uint32_t)height : per_rank * BAND;
 }
 
-// Which frames the FAST builds of k_shade can shade: 1..4 lights and an integer exponent 0 <= p <= 256 (Shader::p is 150 as the
-// reference ships it, src/Shader.cpp:10; any light count and exponent are legal there, src/Shader.cpp:192-386) — every shader
-// type qualifies.  Sets FD_FAST_SHADE + the light count in the host copies of the descriptors.
+// Which frames the FAST builds of k_shade can shade: 1..4 lights (Shader::p is 150 as the reference ships it, src/Shader.cpp:10;
+// any light count and exponent are legal there, src/Shader.cpp:192-386) — every shader type qualifies.  An integer exponent
+// 0 <= p <= 256 takes the builds with the exact multiplication chains, any other exponent the builds whose power is pow_cr
+// (FD_GENPOW; not combined with BUMP / DISPLACEMENT batches: those frames take the generic build).  Sets FD_FAST_SHADE + the
+// light count in the host copies of the descriptors.
 void classify_frames(srz_frameset *fs) {
   fs->fast_mask = 0, fs->any_generic = false;
   for (FrameDesc &d : fs->h_frames) {
-    const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && d.p >= 0.0f && d.p <= 256.0f && d.p == std::trunc(d.p);
+    const bool intpow = d.p >= 0.0f && d.p <= 256.0f && d.p == std::trunc(d.p);
     bool bumpy = false;
     for (uint32_t b = 0; b < d.n_batches; ++b) {
       const int sh = fs->h_batches[d.batch_off + b].shader;
       bumpy = bumpy || sh == SRZ_SHADER_BUMP || sh == SRZ_SHADER_DISPLACEMENT;
     }
-    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | (7u << FD_NL_SHIFT))) |
-              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u)) : 0u);
+    const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && (intpow || !bumpy);
+    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | (7u << FD_NL_SHIFT))) |
+              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (intpow ? 0u : FD_GENPOW)) : 0u);
     if (fast)
-      fs->fast_mask |= 1u << (d.n_lights + (bumpy ? 8u : 0u));
+      fs->fast_mask |= 1u << (d.n_lights + (bumpy ? 8u : 0u) + (intpow ? 0u : 16u));
     else
       fs->any_generic = true;
   }
@@ -553,6 +557,7 @@ int srz_create(srz_ctx **out, int device_id) {
   ctx->device = device_id;
   ctx->env_sub_batch = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0;
   ctx->env_no_vis16 = getenv("SRZ_NO_VIS16") != nullptr;
+  ctx->opt_pool_lazy = getenv("SRZ_POOL_LAZY") != nullptr;
   for (int i = 0; i < MAX_TEX; ++i) ctx->h_tex[i] = TexDesc{nullptr, 0, 0}, ctx->d_texmem[i] = nullptr;
   auto bail = [&](const char *what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
@@ -597,6 +602,13 @@ void srz_destroy(srz_ctx *ctx) {
 }
 
 const char *srz_last_error(const srz_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int srz_set_option(srz_ctx *ctx, int option, int value) {
+  if (!ctx) return SRZ_E_INVALID;
+  if (option != SRZ_OPT_POOL_LAZY) return fail(ctx, SRZ_E_INVALID, "srz_set_option: unknown option " + std::to_string(option));
+  ctx->opt_pool_lazy = value != 0;
+  return SRZ_OK;
+}
 
 int srz_set_shard(srz_ctx *ctx, int rank, int world) {
   if (!ctx) return SRZ_E_INVALID;
@@ -693,7 +705,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     tri_off += nt, light_off += fr.n_lights, batch_off += fr.n_batches;
   }
   fs->total_tris = tri_off, fs->total_lights = light_off, fs->total_groups = group_off;
-  fs->pool_sized = getenv("SRZ_POOL_LAZY") != nullptr; // (diagnostic / tests: no first-render sizing — the pool only follows the previous render's demand)
+  fs->pool_sized = ctx->opt_pool_lazy; // (SRZ_OPT_POOL_LAZY: no first-render sizing — the pool only follows the previous renders' demand)
   classify_frames(fs);
 
   // stage host copies (pinned not needed: one-time upload)
@@ -1331,6 +1343,7 @@ int srz_frameset_allgather_inplace(srz_ctx *ctx, srz_comm *c, const srz_frameset
 
 size_t srz_frameset_gathered_row_offset(const srz_ctx *ctx, const srz_frameset *fs, int what, int frame, int plane, int row) {
   if (!fs || frame < 0 || frame >= fs->n_frames || row < 0 || row >= fs->height) return (size_t)-1;
+  if (what != SRZ_EXCHANGE_PLANES && what != SRZ_EXCHANGE_BGR8) return (size_t)-1;
   const size_t planes = what == SRZ_EXCHANGE_BGR8 ? 1u : 4u;
   if (plane < 0 || (size_t)plane >= planes) return (size_t)-1;
   const size_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (size_t)fs->width * 3u : (size_t)fs->width * sizeof(float);

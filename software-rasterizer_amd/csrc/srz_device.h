@@ -24,7 +24,9 @@ constexpr uint32_t CNT_STRIDE = 32;
 // FrameDesc::flags, internal (set by the host): 1..4 lights and an integer exponent 0..256 → the FAST build of k_shade for that count
 constexpr uint32_t FD_FAST_SHADE = 0x100u, FD_NL_SHIFT = 9; // (+ the light count 1..4 in bits 9..11)
 constexpr uint32_t FD_BUMPY = 0x1000u;                   // some batch of the frame is BUMP / DISPLACEMENT (FAST builds with those variants)
-constexpr uint32_t SHADE_KIND_GENERIC = 8;               // k_shade builds: kinds 0..3 = FAST for 1..4 lights, 4..7 = the same + BUMPY, 8 = generic
+constexpr uint32_t FD_GENPOW = 0x2000u;                  // the exponent is not an integer 0..256: FAST builds whose power is pow_cr (ocml pow in binary64)
+constexpr uint32_t SHADE_KIND_GENERIC = 12;              // k_shade builds: kinds 0..3 = FAST for 1..4 lights, 4..7 = the same + BUMPY,
+                                                         // 8..11 = FAST for 1..4 lights with any exponent (GENPOW), 12 = generic
 constexpr uint32_t N_WORK_LISTS = 8 * (SHADE_KIND_GENERIC + 1);
 constexpr uint32_t UNLISTED = 0xffffffffu; // tile_off of a tile whose list did not fit the record pool
 // Binning is O(triangles): k_setup / k_chunks sort every GROUP of GROUP_TRIS (512) consecutive triangles by the 32-row bands their

@@ -226,15 +226,19 @@ __device__ __forceinline__ float pow_int_cr(float x, float p) {
 }
 // Compile-time knowledge a shading variant may have (k_shade picks the variant per 64-pixel chunk, wave-uniformly):
 //   SH   >= 0: every pixel of the chunk uses shader type SH; -1: per-pixel type (sd.shader)
-//   NL   >  0: the frame has exactly NL lights (1..4) and an integer exponent 0 <= p <= 256 (decided on the host): the light loop
-//              is unrolled, the light constants sit in SGPRs, and the exponent is the fixed chain for p = 150 (Shader::p as the
-//              reference ships it, src/Shader.cpp:10) or the scalar square-and-multiply loop;  0: run-time count, any exponent
+//   NL   >  0: the frame has exactly NL lights (1..4) (decided on the host): the light loop is unrolled, the light constants sit
+//              in SGPRs;  0: run-time count
+//   NL   < 0 : the same for -NL lights, but the exponent is NOT an integer 0..256 (Shader::p is a mutable static in the reference,
+//              src/Shader.cpp:10: any value is legal): the power is pow_cr, as in the generic build.  With NL > 0 the exponent is
+//              an integer 0 <= p <= 256: the fixed chain for p = 150 (the value the reference ships) or the scalar
+//              square-and-multiply loop
 template <int NL> __device__ __forceinline__ float pow_frame(float x, float p) {
   if constexpr (NL > 0)
     return p == 150.0f ? pow150_cr(x) : pow_int_cr(x, p); // (wave-uniform branch: p is a per-frame scalar)
   else
     return pow_cr(x, p);
 }
+template <int NL> constexpr int light_count() { return NL < 0 ? -NL : NL; } // lights known at compile time (0: run-time count)
 
 __device__ __forceinline__ int32_t cvt_rne_i32(float f) {
   if (!(f >= -2147483648.0f && f < 2147483648.0f)) return INT32_MIN;
@@ -395,17 +399,30 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 // and leaves no trace, so pixels that are CERTAINLY outside need not be tested — and a tile or band the triangle certainly
 // misses need not list it.  slab_extent gives the extent along u of (triangle ∩ slab lo <= w <= hi), (u, w) = (x, y) or (y, x),
 // from the vertices inside the slab and the edges' crossings of its two bounds (+inf / -inf when the triangle misses it).
-// CONSERVATIVE: a pixel can pass the rounded inside tests (cover_v / cover_s) only within a distance eps of the true triangle —
-// the edge functions are wrong by < 2^-21 D^2 (D = the vertices' extent: every operand is a difference within the box), the
-// barycentrics by that over |area2| — so with D^2 <= 256 |area2| eps < 2^-11 D; tight_margin returns false otherwise (slivers,
-// non-finite or huge coordinates: the plain box is used).  Slabs and extents are widened by m = D / 512 + 1 / 64, which also
-// covers v_rcp's error in the crossings (2^-22 of a length <= D).
+// CONSERVATIVE: a pixel can pass the rounded inside tests (cover_v / cover_s) only within a distance eps of the true triangle.
+// With D = the vertices' extent and R = D + 1 >= every |pixel - vertex| component of a TESTED pixel (the box starts at
+// trunc(min): up to one pixel before the extent, never behind it — guaranteed by the `near` test below, which sends triangles
+// whose clamped box lies away from their extent, i.e. wholly off screen on an axis, to the plain box: there the operands grow
+// with the distance to the screen, not with D), u = 2^-24:
+//   S test (signs of AB x AP): products <= D R, |error| < 2^-22 D R; a pixel delta outside edge AB has |e| = delta |AB|, and
+//       |AB| >= |area2| / (sqrt2 D) >= D / 362 under the sliver guard D^2 <= 256 |area2|, so eps < 2^-13.5 R;
+//   V test (signs of alpha, beta, 1 - (alpha + beta)): aPBC = fmsub(PBx,PCy,PCx*PBy) has products <= R^2, |error| < 2^-21.7 R^2,
+//       and the multiplication by v_inv keeps its sign: eps < 2^-21.7 R^2 * 362 / D = 2^-13.2 R^2 / D; for gamma the two errors
+//       add and v_inv itself is off by <= 2^-13.7 relative (its operands are <= D, |area2| >= D^2 / 256):
+//       eps < 2^-13.2 D + 2^-12.2 R^2 / D.
+// Both stay below m = D / 512 + 1 / 64 for every D >= 2^-5 (at D = 2^-5: 2^-7.1; large D: 2^-11 D) — smaller triangles (their
+// boxes are at most 2 x 2 pixels: nothing to gain), slivers, non-finite or > 2^20 coordinates keep the plain box.  m also covers
+// v_rcp's error in the crossings (2^-22 of a length <= D).
 // ================================================================================================================
-__device__ __forceinline__ bool tight_margin(float ax, float ay, float bx, float by, float cx, float cy, float area2, float &m) {
-  const float D = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ax, bx), cx) - __builtin_fminf(__builtin_fminf(ax, bx), cx),
-                                  __builtin_fmaxf(__builtin_fmaxf(ay, by), cy) - __builtin_fminf(__builtin_fminf(ay, by), cy));
+__device__ __forceinline__ bool tight_margin(float ax, float ay, float bx, float by, float cx, float cy, float area2, int bsx, int bsy,
+                                             int bex, int bey, float &m) {
+  const float mnx = __builtin_fminf(__builtin_fminf(ax, bx), cx), mxx = __builtin_fmaxf(__builtin_fmaxf(ax, bx), cx);
+  const float mny = __builtin_fminf(__builtin_fminf(ay, by), cy), mxy = __builtin_fmaxf(__builtin_fmaxf(ay, by), cy);
+  const float D = __builtin_fmaxf(mxx - mnx, mxy - mny);
   m = __builtin_fmaf(D, 0.001953125f, 0.015625f);
-  return D * D <= 256.0f * __builtin_fabsf(area2) && D <= 1048576.0f; // (false for NaN / inf)
+  // the clamped box [bsx, bex] x [bsy, bey] lies inside [min - 1, max] of the vertices on both axes (conversions are exact)
+  const bool near = ((float)bsx + 1.0f >= mnx) & ((float)bex <= mxx) & ((float)bsy + 1.0f >= mny) & ((float)bey <= mxy);
+  return near && D * D <= 256.0f * __builtin_fabsf(area2) && D <= 1048576.0f && D >= 0.03125f; // (false for NaN / inf)
 }
 __device__ __forceinline__ void slab_extent(float au, float aw, float bu, float bw, float cu, float cw, float lo, float hi, float &mn,
                                             float &mx) {
@@ -489,7 +506,8 @@ __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t
       float m = 0.0f;
       const bool tight = P != nullptr && nb[k] > 0 &&
                          tight_margin(P[k][0], P[k][1], P[k][3], P[k][4], P[k][6], P[k][7],
-                                      (P[k][3] - P[k][0]) * (P[k][7] - P[k][1]) - (P[k][4] - P[k][1]) * (P[k][6] - P[k][0]), m);
+                                      (P[k][3] - P[k][0]) * (P[k][7] - P[k][1]) - (P[k][4] - P[k][1]) * (P[k][6] - P[k][0]), bb[k].sx,
+                                      bb[k].sy, bb[k].ex, bb[k].ey, m);
       for (int j = 0; j < nb[k]; ++j) {
         uint32_t xr_j = xr;
         if (tight) {
@@ -846,7 +864,8 @@ template <class M, int SH, int NL>
 __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
   const int shader = SH >= 0 ? SH : sd.shader;
-  const uint32_t n_lights = NL > 0 ? (uint32_t)NL : K.n_lights;
+  constexpr int NLC = light_count<NL>();
+  const uint32_t n_lights = NLC > 0 ? (uint32_t)NLC : K.n_lights;
   float c0 = 1.0f, c1 = 1.0f, c2 = 1.0f;
   if (shader == SRZ_SHADER_NORMAL) {
     c0 = (nx + 1.0f) * 0.5f, c1 = (ny + 1.0f) * 0.5f, c2 = (nz + 1.0f) * 0.5f;
@@ -869,14 +888,14 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
       }
     };
     c0 = c1 = c2 = 0.0f;
-    if constexpr (NL > 0) { // every light's colour-independent terms first, the texel only after them
-      LightTerms t[NL];
+    if constexpr (NLC > 0) { // every light's colour-independent terms first, the texel only after them
+      LightTerms t[NLC];
 #pragma unroll
-      for (int l = 0; l < NL; ++l) v_blinn_phong_terms<M, NL>(m, nx, ny, nz, K, K.lights + l, px, py, pz, t[l]);
-      asm volatile("" : "+v"(t[0].cosT), "+v"(t[NL - 1].cosT), "+v"(texel)); // (keeps the decode below the terms)
+      for (int l = 0; l < NLC; ++l) v_blinn_phong_terms<M, NL>(m, nx, ny, nz, K, K.lights + l, px, py, pz, t[l]);
+      asm volatile("" : "+v"(t[0].cosT), "+v"(t[NLC - 1].cosT), "+v"(texel)); // (keeps the decode below the terms)
       decode();
 #pragma unroll
-      for (int l = 0; l < NL; ++l) { // (summed in the lights' order, like the loop below)
+      for (int l = 0; l < NLC; ++l) { // (summed in the lights' order, like the loop below)
         float o0, o1, o2;
         v_blinn_phong_combine(K, K.lights + l, t[l], kd0, kd1, kd2, o0, o1, o2);
         c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
@@ -998,7 +1017,8 @@ template <class M, int SH, int NL>
 __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &sd, float px, float py, float pz, float nx, float ny,
                                         float nz, float u, float v, float &r0, float &r1, float &r2) {
   const int shader = SH >= 0 ? SH : sd.shader;
-  const uint32_t n_lights = NL > 0 ? (uint32_t)NL : K.n_lights;
+  constexpr int NLC = light_count<NL>();
+  const uint32_t n_lights = NLC > 0 ? (uint32_t)NLC : K.n_lights;
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   if (shader == SRZ_SHADER_NORMAL) {
     normalize3(m, nx, ny, nz);
@@ -1006,21 +1026,21 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
   } else if (shader >= SRZ_SHADER_TEXTURE && shader <= SRZ_SHADER_BUMP) {
     float kd0 = 1.0f, kd1 = 1.0f, kd2 = 1.0f;
     float sx = px, sy = py, sz = pz, snx = nx, sny = ny, snz = nz;
-    if constexpr (NL > 0 && (SH == SRZ_SHADER_TEXTURE || SH == SRZ_SHADER_PHONG)) {
+    if constexpr (NLC > 0 && (SH == SRZ_SHADER_TEXTURE || SH == SRZ_SHADER_PHONG)) {
       // FAST build: texel load issued first, every light's colour-independent terms, then the texel and the combination
       bool inside = true;
       uint32_t texel = 0u;
       if (SH == SRZ_SHADER_TEXTURE) texel = s_texel_issue(sd, u, v, inside);
-      LightTerms t[NL];
+      LightTerms t[NLC];
 #pragma unroll
-      for (int l = 0; l < NL; ++l) s_blinn_phong_terms<M, NL>(m, K, sx, sy, sz, snx, sny, snz, K.lights + l, t[l]);
-      asm volatile("" : "+v"(t[0].cosT), "+v"(t[NL - 1].cosT), "+v"(texel));
+      for (int l = 0; l < NLC; ++l) s_blinn_phong_terms<M, NL>(m, K, sx, sy, sz, snx, sny, snz, K.lights + l, t[l]);
+      asm volatile("" : "+v"(t[0].cosT), "+v"(t[NLC - 1].cosT), "+v"(texel));
       if (SH == SRZ_SHADER_TEXTURE) {
         kd0 = m.div255((float)(texel & 0xffu)), kd1 = m.div255((float)((texel >> 8) & 0xffu)), kd2 = m.div255((float)((texel >> 16) & 0xffu));
         if (!inside) kd0 = kd1 = kd2 = 0.0f;
       }
 #pragma unroll
-      for (int l = 0; l < NL; ++l) {
+      for (int l = 0; l < NLC; ++l) {
         float o0, o1, o2;
         s_blinn_phong_combine(K, K.lights + l, t[l], kd0, kd1, kd2, o0, o1, o2);
         c0 = c0 + o0, c1 = c1 + o1, c2 = c2 + o2;
@@ -1049,13 +1069,13 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
   r2 = (q2 == q2) ? (float)(uint32_t)q2 : 0.0f;
 }
 
-// A tile that has an owner goes to one of 72 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
-// the same for frames with BUMP / DISPLACEMENT batches, generic][frame % 8] (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so
+// A tile that has an owner goes to one of 104 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
+// the same for frames with BUMP / DISPLACEMENT batches, the same for frames with a non-integer exponent, generic][frame % 8] (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so
 // every list comes out (roughly) frame by frame.
 __device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
   const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
-                            ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u)
+                            ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u) + ((frame_flags & FD_GENPOW) ? 8u : 0u)
                             : SHADE_KIND_GENERIC;
   const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
   a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = entry;
@@ -1364,7 +1384,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     {
       const float ax = r0.x, ay = r0.y, bx = r0.w, by = r1.x, cx = r1.z, cy = r1.w;
       float m, mn, mx;
-      if (tight_margin(ax, ay, bx, by, cx, cy, s_area, m)) {
+      if (tight_margin(ax, ay, bx, by, cx, cy, s_area, bsx, bsy, bex, bey, m)) {
         int X0 = tx0 + x0, X1 = tx0 + x1, Y0 = ty0 + y0, Y1 = ty0 + y1;
         slab_extent(ax, ay, bx, by, cx, cy, (float)Y0 - m, (float)Y1 + m, mn, mx);
         clip_range(X0, X1, mn, mx, m);
@@ -1905,10 +1925,13 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 //            optimistic FastMath only — a tile where an operand left the fast range is handed back through redo_list.
 //   generic  every other frame with per-pixel generality (any shader, any light count, any exponent), FastMath first and
 //            the IEEE expansions for a tile that needs them; then the tiles the FAST build handed back, IEEE at once.
+//   FASTNL < 0: the FAST build for -FASTNL lights and ANY exponent (pow_cr: ocml's binary64 pow for a non-integer one) — frames that
+//            differ from the common case only in Shader::p keep the per-chunk variants, the unrolled lights and the hoisted texel
 template <bool STATS, int FASTNL, bool BUMPY = false>
 __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
-  constexpr bool FAST = FASTNL > 0;
+  constexpr bool FAST = FASTNL != 0, GENPOW = FASTNL < 0;
   static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
+  static_assert(!(GENPOW && BUMPY), "frames with BUMP / DISPLACEMENT batches and a non-integer exponent take the generic build");
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
   __shared__ uint16_t s_list[TILE * TILE];
@@ -2130,7 +2153,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
   // frames of 1024^2: a persistent grid of 4096 workgroups dealing every 128th tile of a frame 0.78 ms (one stream), a
   // persistent grid drawing tiles from atomic cursors the same on one stream but 7 % slower on two (it holds every CU slot to
   // its end), this walk 0.73 ms.
-  const uint32_t L = (FAST ? (uint32_t)(FASTNL - 1) + (BUMPY ? 4u : 0u) : SHADE_KIND_GENERIC) * 8u + (blockIdx.x & 7u);
+  const uint32_t L = (FAST ? (uint32_t)(light_count<FASTNL>() - 1) + (BUMPY ? 4u : 0u) + (GENPOW ? 8u : 0u) : SHADE_KIND_GENERIC) * 8u + (blockIdx.x & 7u);
   const uint32_t n_work = (FAST || a.force_generic || a.any_generic) ? as_const(a.work_count)[L * CNT_STRIDE] : 0u;
   const SRZ_CAS uint32_t *list = as_const(a.worklist) + (size_t)L * a.work_cap;
   for (uint32_t w = blockIdx.x >> 3; w < n_work; w += gridDim.x >> 3) {
@@ -2370,6 +2393,11 @@ void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t 
   if (fast_mask & 0x400u) hipLaunchKernelGGL((k_shade<false, 2, true>), grid, dim3(256), 0, s, a);
   if (fast_mask & 0x800u) hipLaunchKernelGGL((k_shade<false, 3, true>), grid, dim3(256), 0, s, a);
   if (fast_mask & 0x1000u) hipLaunchKernelGGL((k_shade<false, 4, true>), grid, dim3(256), 0, s, a);
+  // ... and per light count with a non-integer exponent: bit 16 + NL
+  if (fast_mask & 0x20000u) hipLaunchKernelGGL((k_shade<false, -1, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x40000u) hipLaunchKernelGGL((k_shade<false, -2, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x80000u) hipLaunchKernelGGL((k_shade<false, -3, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x100000u) hipLaunchKernelGGL((k_shade<false, -4, false>), grid, dim3(256), 0, s, a);
   // the generic build also serves the tiles the FAST builds hand back: when no frame is generic that is normally
   // nothing, and a small grid does
   dim3 ggrid(any_generic ? grid.x : (grid.x < 128u ? grid.x : 128u));

@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SRZ_LIB_PATH", os.path.join(_PKG, "libsrz.so"))  # (override: A/B of dev builds)
 _lib = None
 
-EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_texture_upload",
+EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_set_option", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
            "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_draw_batch",
@@ -51,6 +51,7 @@ def lib():
         L.srz_last_error.argtypes = [vp]
         L.srz_last_error.restype = C.c_char_p
         L.srz_set_shard.argtypes = [vp, C.c_int, C.c_int]
+        L.srz_set_option.argtypes = [vp, C.c_int, C.c_int]
         L.srz_texture_upload.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
         L.srz_draw.argtypes = [vp, C.c_int, C.POINTER(abi.SrzFrame), fp, fp, fp, fp, C.POINTER(abi.SrzStats)]
         L.srz_draw_batch.argtypes = [vp, C.c_int, C.POINTER(abi.SrzFrame), C.c_int, C.POINTER(fp), C.POINTER(abi.SrzStats)]
@@ -147,7 +148,12 @@ class FrameSet:
         self.ctx._check(lib().srz_frameset_allgather_inplace(self.ctx.h, comm.h, self.h, C.c_void_p(d_gathered_ptr), what, _stream(stream)))
 
     def gathered_row_offset(self, frame, plane, row, what=abi.EXCHANGE_PLANES):
-        return int(lib().srz_frameset_gathered_row_offset(self.ctx.h, self.h, what, frame, plane, row))
+        """byte offset of row `row` of (frame, plane) in a rank-major gathered buffer; IndexError for a frame / plane / row /
+        exchange kind the set does not have (the C call returns (size_t)-1 there: never add THAT to a device pointer)"""
+        off = int(lib().srz_frameset_gathered_row_offset(self.ctx.h, self.h, what, frame, plane, row))
+        if off == 2 ** 64 - 1:
+            raise IndexError(f"gathered_row_offset: frame {frame} / plane {plane} / row {row} / kind {what} out of range")
+        return off
 
     def read_gathered_frame(self, d_gathered_ptr, frame, what=abi.EXCHANGE_PLANES, stream=None):
         """one frame of a gathered buffer as row-major host planes ([4,H,W] float32, or [H,W,3] uint8), de-interleaved by the
@@ -221,6 +227,10 @@ class Context:
 
     def set_shard(self, rank, world):
         self._check(lib().srz_set_shard(self.h, rank, world))
+
+    def set_option(self, option, value):
+        """per-ctx switches for framesets created afterwards (abi.OPT_POOL_LAZY)"""
+        self._check(lib().srz_set_option(self.h, option, int(value)))
 
     def texture_upload(self, tex_id, bgr):
         a = np.ascontiguousarray(bgr, dtype=np.uint8)

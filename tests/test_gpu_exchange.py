@@ -178,7 +178,9 @@ def test_baseline_configs_4_and_5_as_specified_eight_way_sharded(orc, cfg, frame
         assert torch.equal(parallel.gathered_row(gathered, 0, p, y, world), gathered.view(torch.uint8).reshape(-1)[off: off + size * 4].view(torch.float32))
     off8 = fs.gathered_row_offset(0, 0, 77, abi.EXCHANGE_BGR8)
     assert np.array_equal(g8flat[off8: off8 + size * 3].cpu().numpy().reshape(size, 3), orc.resolve8(tuple(refs[0]))[77])
-    assert fs.gathered_row_offset(0, 4, 0) == 2 ** 64 - 1 and fs.gathered_row_offset(0, 0, size) == 2 ** 64 - 1   # out of range
+    for bad in ((0, 4, 0, abi.EXCHANGE_PLANES), (0, 0, size, abi.EXCHANGE_PLANES), (len(frames), 0, 0, abi.EXCHANGE_PLANES), (0, 0, 0, 7)):
+        with pytest.raises(IndexError):   # out of range / unknown exchange kind: the C sentinel (size_t)-1 never reaches a pointer
+            fs.gathered_row_offset(bad[0], bad[1], bad[2], bad[3])
     host = fs.read_gathered_frame(gathered.data_ptr(), 0)
     assert np.array_equal(bits(host), bits(refs[0])), cfg
     host8 = fs.read_gathered_frame(g8.data_ptr(), 0, abi.EXCHANGE_BGR8)

@@ -108,9 +108,10 @@ def test_unified_flag_both_paths(ctx, orc):
 
 def test_pool_overflow_then_growth(ctx, orc, monkeypatch):
     """A few screen-filling triangles make far more (triangle, tile) pairs than the first guess of the list pool.  With the
-    first-render sizing switched off (SRZ_POOL_LAZY, read when the set is created) the first render serves the bands that do
-    not fit through the ordered rasteriser and the next one finds the pool grown.  Both must equal the oracle."""
-    monkeypatch.setenv("SRZ_POOL_LAZY", "1")
+    first-render sizing switched off (srz_set_option SRZ_OPT_POOL_LAZY, applied to sets created afterwards) the first render
+    serves the bands that do not fit through the ordered rasteriser and the next one finds the pool grown.  Both must equal the
+    oracle."""
+    ctx.set_option(abi.OPT_POOL_LAZY, 1)
     w = h = 1024
     n = 24
     t = np.zeros(n, abi.TRI_DTYPE)
@@ -130,6 +131,9 @@ def test_pool_overflow_then_growth(ctx, orc, monkeypatch):
         torch.cuda.synchronize()
         same(out[0].cpu().numpy(), ref, f"pool overflow, render {it}")
     fs.close()
+    ctx.set_option(abi.OPT_POOL_LAZY, 0)
+    with pytest.raises(Exception):
+        ctx.set_option(99, 1)
 
 
 def test_many_small_frames_fill_every_subpool(ctx, orc):
@@ -207,7 +211,7 @@ def adversarial_tris(seed, n, w, h):
     edges exactly through pixel centres and along tile borders, ordinary large triangles — in both windings"""
     rng = np.random.default_rng(seed)
     t = np.zeros(n, abi.TRI_DTYPE)
-    kind = rng.integers(0, 7, n)
+    kind = rng.integers(0, 9, n)
     c = rng.uniform([0, 0], [w, h], (n, 2))
     ang = rng.uniform(0, 2 * np.pi, n)
     d = np.stack([np.cos(ang), np.sin(ang)], 1)
@@ -239,6 +243,19 @@ def adversarial_tris(seed, n, w, h):
     # 6 ordinary large triangles
     k = kind == 6
     xy[k] = (c[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * rng.uniform(30, 400, (n, 1, 1)))[k]
+    # 7 tiny triangles (extent 2^-12 .. 2^-4 pixels) at coordinates < 64 around pixel centres, near the sliver limit of the guard:
+    #   below 2^-5 the tightened rectangles must fall back to the plain box (tight_margin), above it the margin must hold
+    k = kind == 7
+    Dt = (2.0 ** rng.uniform(-12, -4, n))[:, None]
+    c7 = np.round(rng.uniform([0, 0], [64, 64], (n, 2))) + rng.uniform(-1, 1, (n, 2)) * Dt
+    xy[k] = np.stack([c7, c7 + d * Dt, c7 + d * Dt * rng.uniform(0, 1, (n, 1)) + nrm * Dt * (2.0 ** rng.uniform(-7.5, 0, n))[:, None]], 1)[k]
+    # 8 small or ulp-sized triangles 1e4 .. 1e7 pixels off screen on ONE axis: the clamped box is an edge column / row at a
+    #   distance from the triangle that has nothing to do with its extent (plain box there)
+    k = kind == 8
+    off = np.zeros((n, 2))
+    off[np.arange(n), rng.integers(0, 2, n)] = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(4, 7, n)
+    D8 = (10.0 ** rng.uniform(-3, 2.5, n))[:, None, None]
+    xy[k] = ((c + off)[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * D8)[k]
     flip = rng.random(n) < 0.5
     xy[flip] = xy[flip][:, ::-1]
     t["pos"][:, :, :2] = xy

@@ -14,12 +14,15 @@ F = np.float32
 TILE = 32
 
 
-def tight_margin(p, area2):
-    """(ok, m) as the device function: D = the vertices' extent, ok iff D^2 <= 256 |area2| and D <= 2^20"""
-    d = max(F(p[:, 0].max()) - F(p[:, 0].min()), F(p[:, 1].max()) - F(p[:, 1].min()))
-    d = F(d)
+def tight_margin(p, area2, box):
+    """(ok, m) as the device function: D = the vertices' extent, ok iff the clamped box (sx, sy, ex, ey) lies within
+    [min - 1, max] of the vertices on both axes, D^2 <= 256 |area2| and 2^-5 <= D <= 2^20"""
+    mnx, mxx, mny, mxy = F(p[:, 0].min()), F(p[:, 0].max()), F(p[:, 1].min()), F(p[:, 1].max())
+    d = F(max(F(mxx - mnx), F(mxy - mny)))
     m = F(d * F(0.001953125) + F(0.015625))
-    ok = bool(F(d * d) <= F(F(256.0) * abs(F(area2)))) and bool(d <= F(1048576.0))
+    sx, sy, ex, ey = box
+    near = F(F(sx) + F(1.0)) >= mnx and F(ex) <= mxx and F(F(sy) + F(1.0)) >= mny and F(ey) <= mxy
+    ok = bool(near) and bool(F(d * d) <= F(F(256.0) * abs(F(area2)))) and bool(d <= F(1048576.0)) and bool(d >= F(0.03125))
     return ok, m
 
 
@@ -62,7 +65,7 @@ def walked_rect(p, tx, ty, W, H):
         return None
     abx, aby, acx, acy = F(x[1] - x[0]), F(y[1] - y[0]), F(x[2] - x[0]), F(y[2] - y[0])
     area2 = F(F(abx * acy) - F(aby * acx))
-    ok, m = tight_margin(p, area2)
+    ok, m = tight_margin(p, area2, (bsx, bsy, bex, bey))
     if ok:
         mn, mx = slab_extent(x, y, F(F(Y0) - m), F(F(Y1) + m))
         X0, X1 = clip_range(X0, X1, mn, mx, m)
@@ -75,7 +78,7 @@ def walked_rect(p, tx, ty, W, H):
 
 def shapes(rng, n, W, H):
     """the adversarial families of tests/test_gpu_raster_paths.py, one triangle each"""
-    kind = rng.integers(0, 7, n)
+    kind = rng.integers(0, 9, n)
     c = rng.uniform([0, 0], [W, H], (n, 2))
     ang = rng.uniform(0, 2 * np.pi, n)
     d = np.stack([np.cos(ang), np.sin(ang)], 1)
@@ -99,6 +102,20 @@ def shapes(rng, n, W, H):
     xy[k] = (np.round((c[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * rng.uniform(2, 100, (n, 1, 1))) / grid) * grid)[k]
     k = kind == 6
     xy[k] = (c[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * rng.uniform(1, 120, (n, 1, 1)))[k]
+    # 7 tiny triangles, D in [2^-12, 2^-4], at coordinates < 64 (fine float grid) around pixel centres, near the sliver limit
+    #   D^2 = 256 |area2| (height = D / 128 .. D): where the margin's constant is tightest
+    k = kind == 7
+    Dt = (2.0 ** rng.uniform(-12, -4, n))[:, None]
+    c7 = np.round(rng.uniform([0, 0], [min(W, 64), min(H, 64)], (n, 2))) + rng.uniform(-1, 1, (n, 2)) * Dt
+    xy[k] = np.stack([c7, c7 + d * Dt, c7 + d * Dt * rng.uniform(0, 1, (n, 1)) + nrm * Dt * (2.0 ** rng.uniform(-7.5, 0, n))[:, None]], 1)[k]
+    # 8 small or ulp-sized triangles 1e4 .. 1e7 pixels off screen on ONE axis (the clamped box is an edge column / row)
+    k = kind == 8
+    off = np.zeros((n, 2))
+    axis = rng.integers(0, 2, n)
+    off[np.arange(n), axis] = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(4, 7, n)
+    c8 = c + off
+    D8 = (10.0 ** rng.uniform(-3, 2.5, n))[:, None, None]
+    xy[k] = (c8[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * D8)[k]
     return xy.astype(np.float32)
 
 
@@ -131,7 +148,7 @@ def test_every_covered_pixel_lies_in_the_walked_rectangle(orc, seed, flags):
                     sx, ex = int(np.clip(pf[:, 0].min(), 0, W - 1)), int(np.clip(pf[:, 0].max(), 0, W - 1))
                     sy, ey = int(np.clip(pf[:, 1].min(), 0, H - 1)), int(np.clip(pf[:, 1].max(), 0, H - 1))
                     a2 = F(F(F(pf[1, 0] - pf[0, 0]) * F(pf[2, 1] - pf[0, 1])) - F(F(pf[1, 1] - pf[0, 1]) * F(pf[2, 0] - pf[0, 0])))
-                    okb, mb = tight_margin(pf, a2)
+                    okb, mb = tight_margin(pf, a2, (sx, sy, ex, ey))
                     if okb:
                         mn, mx = slab_extent(pf[:, 0], pf[:, 1], F(F(max(ty * TILE, sy)) - mb), F(F(min(ty * TILE + TILE - 1, ey)) + mb))
                         sx, ex = clip_range(sx, ex, mn, mx, mb)
