@@ -1070,48 +1070,53 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
 }
 
 // A tile that has an owner goes to one of 104 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
-// the same for frames with BUMP / DISPLACEMENT batches, the same for frames with a non-integer exponent, generic][frame % 8] (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so
-// every list comes out (roughly) frame by frame.
-__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry) {
+// the same for frames with BUMP / DISPLACEMENT batches, the same for frames with a non-integer exponent, generic][frame % 8]
+// (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so every list comes
+// out (roughly) frame by frame.  An entry = {frame * tiles_per_frame + tile, V pixels | S pixels << 16}: the lengths of the tile's
+// two pixel lists travel with it.
+__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry, uint32_t counts) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
   const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
                             ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u) + ((frame_flags & FD_GENPOW) ? 8u : 0u)
                             : SHADE_KIND_GENERIC;
   const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
-  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = entry;
+  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint2(entry, counts);
 }
 
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
 constexpr uint32_t S_CLASS_BIT = 0x80000000u;
 
-// The owner-id plane holds one id per pixel of the owned tiles: 32 bits (index | S_CLASS_BIT, NO_TRI = nobody), or — when
-// every frame of the set has fewer than 32768 triangles (RenderArgs::vis16) — 16 bits (index | 0x8000, 0xffff = nobody) at the
-// same pixel index: half the bytes k_raster writes and k_shade reads back (0.19 GB of a 256-frame step of config 2).
-__device__ __forceinline__ uint32_t id_pack16(uint32_t id) { return id == NO_TRI ? 0xffffu : ((id & 0x7fffu) | ((id >> 16) & 0x8000u)); }
-__device__ __forceinline__ uint32_t id_unpack16(uint32_t h) { return h == 0xffffu ? NO_TRI : ((h & 0x7fffu) | ((h & 0x8000u) << 16)); }
-__device__ __forceinline__ void vis_store4(uint32_t *vis, size_t e, const uint4 &id, bool v16) { // e % 4 == 0
-  if (v16) {
-    const u32x2 w = {id_pack16(id.x) | (id_pack16(id.y) << 16), id_pack16(id.z) | (id_pack16(id.w) << 16)};
-    *reinterpret_cast<u32x2 *>(reinterpret_cast<uint16_t *>(vis) + e) = w;
-  } else {
-    *reinterpret_cast<uint4 *>(vis + e) = id;
+// What the rasterisers hand to k_shade per OWNED tile: its visible pixels, already compacted by semantics class into two
+// lists in the tile's slot of `vis` (PIX_SLOT dwords): V pixels at [0, nV), S pixels at [nV, nV + nS), each list in row-major
+// pixel order, one entry = pixel (ly * 32 + lx, 10 bits) | owner triangle << 10.  k_shade starts a tile at its shading chunks:
+// no owner-id plane to load, classify and compact (that front end was a quarter of its wave time, DESIGN.md / NOTEBOOK.md).
+// Frames with 2^22 triangles or more (RenderArgs::wide_ids) store {pixel, owner} as two dwords per entry instead.
+constexpr uint32_t PIX_SLOT = TILE * TILE, PIX_BITS = 10, PIX_MASK = PIX_SLOT - 1u;
+// One strip of 8 rows x 32 pixels, 4 consecutive pixels per lane (lane → row lane / 8, columns (lane % 8) * 4 ..): the strip's
+// V | S << 16 pixel counts per lane and their inclusive wave scan
+__device__ __forceinline__ uint32_t strip_counts(const uint4 &id, uint32_t &incl) {
+  const uint32_t k[4] = {id.x, id.y, id.z, id.w};
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c += k[j] == NO_TRI ? 0u : ((k[j] & S_CLASS_BIT) ? 0x10000u : 1u);
+  incl = wave_scan_add(c);
+  return c;
+}
+// the lane's entries of one strip into the LDS stage: V from oV on, S from oS on (both already include the lists' bases).
+// Branch-free: a pixel nobody owns stores to the dummy slot `dump` (behind the lists: entry PIX_SLOT + lane)
+template <bool WIDE>
+__device__ __forceinline__ void strip_scatter(uint32_t *stage, const uint4 &id, uint32_t p0, uint32_t oV, uint32_t oS, uint32_t dump) {
+  const uint32_t k[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool own = k[j] != NO_TRI, isS = (int32_t)k[j] < 0 && own; // (NO_TRI has bit 31 set too)
+    const uint32_t o = own ? (isS ? oS : oV) : dump;
+    if (WIDE)
+      *reinterpret_cast<u32x2 *>(stage + 2 * o) = u32x2{p0 + (uint32_t)j, k[j] & ~S_CLASS_BIT};
+    else
+      stage[o] = (p0 + (uint32_t)j) | (k[j] << PIX_BITS); // (the class bit is shifted out)
+    oV += (own && !isS) ? 1u : 0u, oS += isS ? 1u : 0u;
   }
-}
-__device__ __forceinline__ void vis_store1(uint32_t *vis, size_t e, uint32_t id, bool v16) {
-  if (v16)
-    reinterpret_cast<uint16_t *>(vis)[e] = (uint16_t)id_pack16(id);
-  else
-    vis[e] = id;
-}
-__device__ __forceinline__ uint4 vis_load4(const uint32_t *vis, size_t e, bool v16) { // e % 4 == 0
-  if (v16) {
-    const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint16_t *>(vis) + e);
-    return make_uint4(id_unpack16(w.x & 0xffffu), id_unpack16(w.x >> 16), id_unpack16(w.y & 0xffffu), id_unpack16(w.y >> 16));
-  }
-  return *reinterpret_cast<const uint4 *>(vis + e);
-}
-__device__ __forceinline__ uint32_t vis_load1(const uint32_t *vis, size_t e, bool v16) {
-  return v16 ? id_unpack16(reinterpret_cast<const uint16_t *>(vis)[e]) : vis[e];
 }
 
 // Everything the shader needs about the owner triangle of one pixel, fetched in ONE round trip (7 independent loads)
@@ -1336,7 +1341,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
   const size_t row0 = (size_t)lb * BAND;
   float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
-  uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
 
   // (the first 64 indices of the tile's list are loaded under the tile init)
   const uint32_t i_first = as_const(a.pool)[off + min((uint32_t)lane, cnt - 1u)];
@@ -1579,7 +1583,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   // ---- phase C: decode the keys, write out ------------------------------------------------------------------------
   //  some final key needs the ordered algorithm  : the tile goes to k_raster_slow, nothing is written here
   //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
-  //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
+  //  owned tile          : z plane + the tile's two pixel lists, and the tile is queued for k_shade (which writes the 3 colour planes)
   float4 z4[ITS];
   uint4 id4[ITS];
   bool any_owner = false, redo = false;
@@ -1599,6 +1603,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       id[k] = (tb[k] & 0x80000000u) ? (tb[k] & 0x7fffffffu) : (tb[k] == TB_NONE ? NO_TRI : ((0x7ffffffeu - tb[k]) | S_CLASS_BIT));
       any_owner |= tb[k] != TB_NONE;
     }
+    // (pixels of the tile beyond the frame's edge never got a fragment: their rectangles are clipped to tx1 / ty1)
     z4[it] = make_float4(zz[0], zz[1], zz[2], zz[3]);
     id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
   }
@@ -1625,13 +1630,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       float *gz = out0 + (size_t)ly * W + x4;
       const bool full = vec_ok && x4 + 3 <= tx1;
       if (tile_has_owner) {
-        const size_t ge = (size_t)(vis0 - a.vis) + (size_t)ly * W + x4;
         if (full) {
-          store_nt(gz, z4[it]);                      // final: k_shade recomputes the depth it needs from the owner triangle
-          vis_store4(a.vis, ge, id4[it], a.vis16 != 0u); // re-read by k_shade: keep it cacheable
+          store_nt(gz, z4[it]); // final: k_shade recomputes the depth it needs from the owner triangle
         } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, vis_store1(a.vis, ge + K_, id4[it].M, a.vis16 != 0u);
+  if (x4 + K_ <= tx1) gz[K_] = z4[it].M;
           SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
         }
@@ -1650,8 +1653,64 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       }
     }
   }
+  if (!tile_has_owner) return; // workgroup-uniform
+  // ---- the tile's visible pixels, compacted by class: V list, then S list (see PIX_SLOT) -----------------------------------
+  // every pixel's owner is in registers (id4): per 8-row strip a packed count + DPP scan, the entries assembled in the dead
+  // keys' LDS and stored as ONE coalesced run of 16-byte stores (cacheable: k_shade reads them back)
+  uint32_t cnt2[ITS], incl2[ITS], baseV[ITS], baseS[ITS], nV = 0, nS = 0;
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) cnt2[it] = strip_counts(id4[it], incl2[it]);
+  if constexpr (WAVES > 1) { // (one strip per wave: the strips' totals through LDS)
+    if (lane == 63) s_mark_x[wave] = incl2[0];
+    __syncthreads(); // (also: every wave has read its keys — the stage below overwrites them)
+    uint32_t bv = 0, bs = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < WAVES; ++w2) {
+      const uint32_t t2 = s_mark_x[w2];
+      bv += w2 < wave ? (t2 & 0xffffu) : 0u, bs += w2 < wave ? (t2 >> 16) : 0u, nV += t2 & 0xffffu, nS += t2 >> 16;
+    }
+    baseV[0] = bv, baseS[0] = bs;
+  } else {
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const uint32_t t2 = (uint32_t)rl_i((int)incl2[it], 63);
+      baseV[it] = nV, baseS[it] = nS, nV += t2 & 0xffffu, nS += t2 >> 16;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the key reads above stay in front of the stage's stores)
+    __builtin_amdgcn_wave_barrier();
+  }
+  uint32_t *const stage = reinterpret_cast<uint32_t *>(s_key);
+  const bool wide = a.wide_ids != 0u; // wave-uniform
+  static_assert(sizeof(s_key) >= 2 * (PIX_SLOT + 32) * 4 && sizeof(s_key) >= (PIX_SLOT + 64 * WAVES) * 4, "the stage holds the lists and the dummy slots");
+  auto scatter_all = [&](auto wide_c) {
+    constexpr bool WIDE = decltype(wide_c)::value;
+    // dummy slots for the pixels nobody owns: the entries behind the lists (the keys' block is 2112 dwords: 1088 more narrow
+    // entries, or 32 wide ones which the lanes share — nobody reads a dummy)
+    const uint32_t dump = WIDE ? (PIX_SLOT + ((uint32_t)threadIdx.x & 31u)) : (PIX_SLOT + (uint32_t)threadIdx.x);
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const uint32_t p0 = (uint32_t)(((wave * ITS + it) * 8 + (lane >> 3)) * TILE + (lane & 7) * 4), ex = incl2[it] - cnt2[it];
+      strip_scatter<WIDE>(stage, id4[it], p0, baseV[it] + (ex & 0xffffu), nV + baseS[it] + (ex >> 16), dump);
+    }
+  };
+  if (wide)
+    scatter_all(std::true_type{});
+  else
+    scatter_all(std::false_type{});
+  if constexpr (WAVES > 1) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  {
+    const uint32_t n_dw = (nV + nS) << (wide ? 1 : 0);
+    uint32_t *dst = a.vis + ((size_t)frame * tiles_per_frame + tile) * ((size_t)PIX_SLOT << (wide ? 1 : 0));
+    for (uint32_t i = threadIdx.x * 4u; i < n_dw; i += 64u * WAVES * 4u) // (a 16-byte unit may end past the list: stage and slot are PIX_SLOT long)
+      *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(stage + i);
+  }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
-  if (tile_has_owner && lane == 0 && wave == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile);
+  if (lane == 0 && wave == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, nV | (nS << 16));
 }
 
 // ================================================================================================================
@@ -1664,8 +1723,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
-  __shared__ __attribute__((aligned(16))) float zl[TILE * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint32_t il[TILE * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_planes[2 * TILE * LDS_STRIDE + 128]; // z plane | owner plane (one block: the pixel lists' stage) | dummy slots
+  float *const zl = reinterpret_cast<float *>(s_planes);
+  uint32_t *const il = s_planes + TILE * LDS_STRIDE;
   const int lane = threadIdx.x & 63;
   const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
   const uint32_t n_slow = *as_const(a.slow_count);
@@ -1685,7 +1745,6 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
     const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
     const size_t row0 = (size_t)lb * BAND;
     float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W;
-    uint32_t *vis0 = a.vis + ((size_t)frame * a.local_rows + row0) * (size_t)W;
     // ---- phase A: tile init (fused clear → +inf, else load the in/out z plane) -------------------------------
     for (int i = lane; i < TILE * TILE; i += 64) {
       const int ly = i >> 5, lx = i & 31;
@@ -1829,14 +1888,11 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         float *gz = out0 + (size_t)ly * W + x4;
         const bool full = vec_ok && x4 + 3 <= tx1;
         if (tile_has_owner) {
-          const uint4 id4 = *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]);
-          const size_t ge = (size_t)(vis0 - a.vis) + (size_t)ly * W + x4;
           if (full) {
             store_nt(gz, z4);
-            vis_store4(a.vis, ge, id4, a.vis16 != 0u);
           } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4.M, vis_store1(a.vis, ge + K_, id4.M, a.vis16 != 0u);
+  if (x4 + K_ <= tx1) gz[K_] = z4.M;
             SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
           }
@@ -1855,7 +1911,35 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         }
       }
     }
-    if (tile_has_owner && lane == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile);
+    if (tile_has_owner) { // the tile's two pixel lists (as k_raster): assembled in the z plane's LDS, whose values have left
+      uint4 id4[4];
+      uint32_t cnt2[4], incl2[4], baseV[4], baseS[4], nV = 0, nS = 0;
+      for (int it = 0; it < 4; ++it) {
+        id4[it] = *reinterpret_cast<const uint4 *>(&il[(it * 8 + (lane >> 3)) * LDS_STRIDE + (lane & 7) * 4]);
+        cnt2[it] = strip_counts(id4[it], incl2[it]);
+        const uint32_t t2 = (uint32_t)rl_i((int)incl2[it], 63);
+        baseV[it] = nV, baseS[it] = nS, nV += t2 & 0xffffu, nS += t2 >> 16;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the z reads of the write-out stay in front of the stage's stores)
+      __builtin_amdgcn_wave_barrier();
+      const bool wide = a.wide_ids != 0u;
+      uint32_t *const stage = s_planes; // (wide lists: 2 x PIX_SLOT dwords = both planes; the owner plane has been read into id4)
+      static_assert(TILE * LDS_STRIDE == (int)PIX_SLOT, "the stage of a wide list spans both planes");
+      for (int it = 0; it < 4; ++it) { // (dummy slots of the unowned pixels: behind the lists)
+        const uint32_t p0 = (uint32_t)((it * 8 + (lane >> 3)) * TILE + (lane & 7) * 4), ex = incl2[it] - cnt2[it];
+        if (wide)
+          strip_scatter<true>(stage, id4[it], p0, baseV[it] + (ex & 0xffffu), nV + baseS[it] + (ex >> 16), PIX_SLOT + (uint32_t)lane);
+        else
+          strip_scatter<false>(stage, id4[it], p0, baseV[it] + (ex & 0xffffu), nV + baseS[it] + (ex >> 16), PIX_SLOT + (uint32_t)lane);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t n_dw = (nV + nS) << (wide ? 1 : 0);
+      uint32_t *dst = a.vis + (size_t)entry * ((size_t)PIX_SLOT << (wide ? 1 : 0));
+      for (uint32_t i = (uint32_t)lane * 4u; i < n_dw; i += 256u) *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(stage + i);
+      if (lane == 0) work_append(a, fd->flags, frame, entry, nV | (nS << 16));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
   }
   if (STATS) {
@@ -1869,8 +1953,8 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
 
 // ================================================================================================================
 // k_shade — VISIBILITY-FIRST SHADING: one workgroup per owned tile (persistent grid over the worklist).
-// The tile's owned pixels are first COMPACTED by semantics class into two dense LDS lists (V from the front, S from
-// the back), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
+// The tile's owned pixels arrive COMPACTED by semantics class (the rasteriser's write-out made the two lists: V pixels, then S
+// pixels), so every wave runs one of the two shader variants with full lanes instead of both under divergence;
 // colours go to LDS planes and leave as coalesced 16-byte stores.
 // ================================================================================================================
 // k_clear — the fused clear of every tile NO bbox reaches (k_bin's tile counts), i.e. most of the framebuffer.  It runs
@@ -1933,20 +2017,28 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
   static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
   static_assert(!(GENPOW && BUMPY), "frames with BUMP / DISPLACEMENT batches and a non-integer exponent take the generic build");
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_ids[TILE * TILE];
-  __shared__ uint16_t s_list[TILE * TILE];
-  __shared__ uint32_t s_wcnt[4][2]; // per wave: V-class and S-class pixels among its 256
-  __shared__ uint32_t s_flag;       // "some operand left FastMath's range"
+  __shared__ __attribute__((aligned(16))) uint32_t s_ent[PIX_SLOT];     // the tile's pixel lists (wide lists are read from global memory per chunk)
+  __shared__ uint32_t s_flag;                                           // "some operand left FastMath's range"
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long n_vis = 0, n_vis_tex = 0;
   const uint32_t tpf = a.n_local_bands * a.tiles_x;
+  const bool wide = a.wide_ids != 0u; // wave-uniform
 
-  // ---- one owned tile: entry e of frame f's work list.  mode: 0 = FAST variants, 1 = generic (FastMath, then IEEE if
-  //      needed), 2 = IEEE at once -----------------------------------------------------------------------------------------
-  auto shade_tile = [&](const uint32_t f, const uint32_t e, auto mode_c) {
+  // ---- one owned tile: x = its work-list entry {frame * tiles_per_frame + tile, V pixels | S pixels << 16}.  mode: 0 = FAST
+  //      variants, 1 = generic (FastMath, then IEEE if needed), 2 = IEEE at once ------------------------------------------------
+  auto shade_tile = [&](const u32x2 x, auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
+    const uint32_t nV = x.y & 0xffffu, nS = x.y >> 16;
+    // ---- 1. the tile's pixel lists (written by the rasteriser: V pixels, then S pixels, row-major each) → LDS, one coalesced
+    //         load whose address needs nothing but the entry: it is in flight under the frame descriptor's scalar loads
+    //         (issued here, parked in LDS only in front of the barrier below)
+    const SRZ_CAS uint32_t *ent_g = as_const(a.vis) + (size_t)x.x * ((size_t)PIX_SLOT << (wide ? 1 : 0));
+    const bool ent_lo = !wide && (uint32_t)tid * 4u < nV + nS;
+    u32x4 ent0 = {0u, 0u, 0u, 0u};
+    if (ent_lo) ent0 = reinterpret_cast<const SRZ_CAS u32x4 *>(ent_g)[tid];
+    const uint32_t f = x.x / tpf, e = x.x % tpf;
     const uint32_t tx = e % a.tiles_x, lb = e / a.tiles_x;
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
     const int W = fd->width, H = fd->height;
@@ -1963,70 +2055,37 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     const size_t row0 = (size_t)lb * BAND;
     float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
-    const uint32_t *vis0 = a.vis + ((size_t)f * a.local_rows + row0) * (size_t)W;
 
-    // ---- 1. load this thread's 4 pixels (owner id, old colour unless fused) into LDS, classify, compact ----------
-    //         (the z plane is not read: the shader's depth is recomputed from the owner triangle with k_raster's own
-    //         operations, which is cheaper than 4 bytes per pixel of HBM read)
+    // ---- 2. the colour staging planes start as what the pixels this call does not own must hold: 0 after the fused clear, else
+    //         the colour already in the framebuffer (the z plane is not read: the shader's depth is recomputed from the owner
+    //         triangle with k_raster's own operations, which is cheaper than 4 bytes per pixel of HBM read)
     const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int y = ty0 + ly, x4 = tx0 + lx4;
     const bool in_tile = y <= ty1 && x4 <= tx1;
     const bool full = in_tile && ((W & 3) == 0) && x4 + 3 <= tx1;
     float *gz = out0 + (size_t)ly * W + x4;
-    const size_t ge = (size_t)(vis0 - a.vis) + (size_t)ly * W + x4;
     float4 C0 = make_float4(0.f, 0.f, 0.f, 0.f), C1 = C0, C2 = C0;
-    uint4 id4 = make_uint4(NO_TRI, NO_TRI, NO_TRI, NO_TRI);
-    if (full) {
-      id4 = vis_load4(a.vis, ge, a.vis16 != 0u);
-      if (!fused) { // keep the colour of pixels this call does not own
+    if (!fused) { // keep the colour of pixels this call does not own
+      if (full) {
         C0 = *reinterpret_cast<const float4 *>(gz + plane);
         C1 = *reinterpret_cast<const float4 *>(gz + 2 * plane);
         C2 = *reinterpret_cast<const float4 *>(gz + 3 * plane);
-      }
-    } else if (in_tile) {
+      } else if (in_tile) {
 #define SRZ_LD(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) {                                                                                                \
-    id4.M = vis_load1(a.vis, ge + K_, a.vis16 != 0u);                                                                  \
-    if (!fused) C0.M = gz[plane + K_], C1.M = gz[2 * plane + K_], C2.M = gz[3 * plane + K_];                           \
-  }
-      SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
+  if (x4 + K_ <= tx1) C0.M = gz[plane + K_], C1.M = gz[2 * plane + K_], C2.M = gz[3 * plane + K_];
+        SRZ_LD(0, x) SRZ_LD(1, y) SRZ_LD(2, z) SRZ_LD(3, w)
 #undef SRZ_LD
+      }
     }
     const int p0 = ly * TILE + lx4;
-    *reinterpret_cast<uint4 *>(&s_ids[p0]) = id4;
     *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
     *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
-    // classify this thread's 4 pixels and compact them BY CLASS into the two lists (V from the front, S from the back):
-    // per-thread counts, one packed wave scan (DPP), the waves' totals through LDS — no atomics, and the lists come out in
-    // row-major pixel order
-    const uint32_t idk[4] = {id4.x, id4.y, id4.z, id4.w};
-    uint32_t cnt2 = 0; // V count | S count << 16 of this thread
-#pragma unroll
-    for (int k = 0; k < 4; ++k) cnt2 += idk[k] == NO_TRI ? 0u : ((idk[k] & S_CLASS_BIT) ? 0x10000u : 1u);
-    const uint32_t incl2 = wave_scan_add(cnt2);
-    if (lane == 63) s_wcnt[wave][0] = incl2 & 0xffffu, s_wcnt[wave][1] = incl2 >> 16;
     if (tid == 0) s_flag = 0;
-    __syncthreads();
-    uint32_t bV = 0, bS = 0, nV = 0, nS = 0; // this wave's first slot in each list, list lengths (all wave-uniform)
-#pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const uint32_t v = s_wcnt[w2][0], sN = s_wcnt[w2][1];
-      bV += w2 < wave ? v : 0u, bS += w2 < wave ? sN : 0u, nV += v, nS += sN;
-    }
-    nV = (uint32_t)__builtin_amdgcn_readfirstlane((int)nV), nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)nS);
-    {
-      uint32_t oV = bV + ((incl2 - cnt2) & 0xffffu), oS = TILE * TILE - 1 - (bS + ((incl2 - cnt2) >> 16));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool own = idk[k] != NO_TRI, isS = own && (idk[k] & S_CLASS_BIT) != 0;
-        if (own) s_list[isS ? oS : oV] = (uint16_t)(p0 + k);
-        oV += (own && !isS) ? 1u : 0u, oS -= isS ? 1u : 0u;
-      }
-    }
+    if (ent_lo) *reinterpret_cast<u32x4 *>(&s_ent[tid * 4]) = ent0;
     __syncthreads();
 
-    // ---- 2. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
+    // ---- 3. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
     const uint32_t cV = (nV + 63) >> 6, cS = (nS + 63) >> 6;
     // (one loop per class: a single loop over both keeps the registers of the V and of the S shader alive together)
@@ -2046,8 +2105,15 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
         if ((c < cV) != isV) continue;
         const uint32_t i = (isV ? c : c - cV) * 64 + lane;
         if (i >= (isV ? nV : nS)) continue;
-        const uint32_t p = s_list[isV ? i : TILE * TILE - 1 - i];
-        const uint32_t id = s_ids[p] & ~S_CLASS_BIT;
+        const uint32_t slot = isV ? i : nV + i;
+        uint32_t p, id;
+        if (wide) { // (>= 2^22 triangles in a frame: not a throughput case)
+          const u32x2 en = reinterpret_cast<const SRZ_CAS u32x2 *>(ent_g)[slot];
+          p = en.x, id = en.y;
+        } else {
+          const uint32_t en = s_ent[slot];
+          p = en & PIX_MASK, id = en >> PIX_BITS;
+        }
         float r0 = 1.f, r1 = 2.f, r2 = 3.f;
         ShadeDesc sd;
         TriFetch tf;
@@ -2116,7 +2182,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
       __syncthreads();
       if (s_flag) { // workgroup-uniform
         if constexpr (MODE == 0) { // hand the tile to the generic build
-          if (tid == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = f * tpf + e;
+          if (tid == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = make_uint2(x.x, x.y);
           skip_write = true;
         } else {
           if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
@@ -2126,7 +2192,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
       }
     }
 
-    // ---- 3. coalesced write-out of the three colour planes ----------------------------------------------------------
+    // ---- 4. coalesced write-out of the three colour planes ----------------------------------------------------------
     if (!skip_write) {
       C0 = *reinterpret_cast<const float4 *>(&s_c[0][p0]);
       C1 = *reinterpret_cast<const float4 *>(&s_c[1][p0]);
@@ -2145,30 +2211,36 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
   };
 
   // Workgroup b (on XCD b % 8) shades entries b/8, b/8 + G/8, ... of work list [this build][b % 8]: the tiles of the frames
-  // that XCD rasterised (its L2 holds their z / owner ids), in frame order.  The grid is LARGE (a tile or two per workgroup),
+  // that XCD rasterised (its L2 holds their pixel lists), in frame order.  The grid is LARGE (a tile or two per workgroup),
   // so the hardware dispatcher hands the work out in order and at tile granularity: all resident workgroups are on the same
-  // few frames at any time (triangles + ids stay cache-resident), a CU slowed by the clear's waves simply receives fewer
+  // few frames at any time (triangles + lists stay cache-resident), a CU slowed by the clear's waves simply receives fewer
   // workgroups, the kernel's tail is a tile long — and, unlike a persistent grid, CU slots keep turning over, which lets the
   // kernels of another stream (LaneRenderer: the next batch's k_bin / k_raster) in beside this one.  Measured on MI355X, 256
   // frames of 1024^2: a persistent grid of 4096 workgroups dealing every 128th tile of a frame 0.78 ms (one stream), a
   // persistent grid drawing tiles from atomic cursors the same on one stream but 7 % slower on two (it holds every CU slot to
   // its end), this walk 0.73 ms.
   const uint32_t L = (FAST ? (uint32_t)(light_count<FASTNL>() - 1) + (BUMPY ? 4u : 0u) + (GENPOW ? 8u : 0u) : SHADE_KIND_GENERIC) * 8u + (blockIdx.x & 7u);
+  const SRZ_CAS u32x2 *list = reinterpret_cast<const SRZ_CAS u32x2 *>(as_const(a.worklist)) + (size_t)L * a.work_cap;
+  // the list's length and this workgroup's first entry are loaded TOGETHER (the entry's index is clamped into the list's
+  // storage; it is used only if it lies below the length): one round trip instead of two before the tile's own loads start
+  uint32_t w = blockIdx.x >> 3;
+  u32x2 x = list[min(w, a.work_cap - 1u)];
   const uint32_t n_work = (FAST || a.force_generic || a.any_generic) ? as_const(a.work_count)[L * CNT_STRIDE] : 0u;
-  const SRZ_CAS uint32_t *list = as_const(a.worklist) + (size_t)L * a.work_cap;
-  for (uint32_t w = blockIdx.x >> 3; w < n_work; w += gridDim.x >> 3) {
-    const uint32_t x = list[w];
+  while (w < n_work) {
+    const u32x2 xc = x;
+    w += gridDim.x >> 3;
+    if (w < n_work) x = list[w];
     if constexpr (FAST)
-      shade_tile(x / tpf, x % tpf, std::integral_constant<int, 0>{});
+      shade_tile(xc, std::integral_constant<int, 0>{});
     else
-      shade_tile(x / tpf, x % tpf, std::integral_constant<int, 1>{});
+      shade_tile(xc, std::integral_constant<int, 1>{});
     __syncthreads(); // LDS is reused by the next tile
   }
   if constexpr (!FAST) { // the tiles the FAST build handed back (it ran before this kernel on the same stream)
     const uint32_t n_redo = *as_const(a.redo_count);
     for (uint32_t i = blockIdx.x; i < n_redo; i += gridDim.x) {
-      const uint32_t x = as_const(a.redo_list)[i];
-      shade_tile(x / tpf, x % tpf, std::integral_constant<int, 2>{});
+      const u32x2 xr = reinterpret_cast<const SRZ_CAS u32x2 *>(as_const(a.redo_list))[i];
+      shade_tile(xr, std::integral_constant<int, 2>{});
       __syncthreads(); // LDS is reused by the next tile
     }
   }

@@ -299,3 +299,33 @@ def test_tight_rectangles_in_the_throughput_build(ctx, orc):
         rc, ref, _ = orc.draw(f)
         assert rc == 0
         same(got[i], ref, f"batch frame {i}")
+
+
+def test_wide_pixel_list_entries(orc, monkeypatch):
+    """frames with 2^22 triangles or more store {pixel, owner} dword pairs in the tiles' pixel lists (RenderArgs::wide_ids);
+    SRZ_WIDE_IDS (read when the ctx is created) forces that form: same planes bit for bit, both rasterisers, batch and single frame"""
+    import srz
+    monkeypatch.setenv("SRZ_WIDE_IDS", "1")
+    c = srz.Context(0)
+    c.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    try:
+        f = scenes.config2(7, size=512)
+        rc, ref, _ = orc.draw(f)
+        assert rc == 0
+        fs = c.frameset([scenes.config2(i, size=512) for i in (7, 8, 9)] * 7)   # 21 frames x 256 tiles: the throughput build
+        out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+        for extra in (0, abi.ORDERED_RASTER):
+            out.fill_(-2.0)
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | extra, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            same(out[0].cpu().numpy(), ref, f"wide entries, batch, flags {extra}")
+            same(out[19].cpu().numpy(), orc.draw(scenes.config2(8, size=512))[1], "wide entries, frame 19")
+        fs.close()
+        fs1 = c.frameset([f])                                                    # one frame: four waves per tile
+        o1 = torch.zeros(fs1.out_shape, dtype=torch.float32, device="cuda")
+        fs1.render(o1.data_ptr(), fs1.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        same(o1[0].cpu().numpy(), ref, "wide entries, single frame")
+        fs1.close()
+    finally:
+        c.close()
