@@ -107,11 +107,11 @@ struct srz_frameset {
   static constexpr int DEMAND_PARTS = 8; // h_pool_heads holds one copy of the allocators' lines per sub-batch of a large render
   uint2 *d_tile_info = nullptr;
   uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr;
-  uint2 *d_redo_list = nullptr; // (its counter is d_slow_count[1])
+  uint4 *d_redo_list = nullptr; // (its counter is d_slow_count[1])
   uint32_t fast_mask = 0;   // bit NL (+ 8 with BUMP / DISPLACEMENT batches, + 16 with a non-integer exponent): some frame is shaded by that FAST build of k_shade (classify_frames)
   bool any_generic = true;  // some frame needs the generic build
   uint32_t *d_vis = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr; // d_vis: the per-tile pixel lists (srz_device.h)
-  uint2 *d_worklist = nullptr;
+  uint4 *d_worklist = nullptr;
   bool wide_ids = false; // some frame has >= 2^22 triangles: two dwords per pixel-list entry
   uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
   uint2 *d_band_ent = nullptr;     // and entries [group][ENT_PER_GROUP]
@@ -758,11 +758,11 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     FS_TRY(dev_alloc((void **)&fs->d_tile_info, sizeof(uint2) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_count, 2 * sizeof(uint32_t)));
-    FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint2) * fs->max_tiles));
+    FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint4) * fs->max_tiles));
   }
   fs->wide_ids = ctx->env_wide_ids || fs->max_tris >= (1u << 22);
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)fs->max_tiles * ((size_t)TILE * TILE << (fs->wide_ids ? 1 : 0))));
-  FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint2) * N_WORK_LISTS * (size_t)(n_frames < 8 ? n_frames : (n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x));
+  FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint4) * N_WORK_LISTS * (size_t)(n_frames < 8 ? n_frames : (n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x));
   FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * CNT_STRIDE * N_WORK_LISTS));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));

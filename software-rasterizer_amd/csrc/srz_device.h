@@ -140,15 +140,16 @@ struct RenderArgs {
   uint32_t any_ordered;          // host hint: SRZ_ORDERED_RASTER is set on the render or on some frame (k_raster_slow gets a large grid)
   uint32_t force_generic;        // every frame is shaded by the generic build of k_shade (counting runs)
   uint32_t any_generic;          // some frame is not FD_FAST_SHADE (else the generic build only serves redo_list)
-  uint2 *redo_list;              // work-list entries of the tiles the FAST builds of k_shade hand to the generic one
+  uint4 *redo_list;              // work-list entries of the tiles the FAST builds of k_shade hand to the generic one
   uint32_t *redo_count;
   uint32_t wide_ids;             // some frame of the set has >= 2^22 triangles: the pixel lists hold {pixel, owner} dword pairs
   uint32_t *vis;                 // per-tile pixel lists [frame][local band][tile x][PIX_SLOT (x 2 if wide_ids) dwords]: the visible
                                  // pixels of an owned tile by class — V entries, then S entries; pixel | owner << 10 — written by the
                                  // rasterisers' write-out, read by k_shade (srz_kernels.hip, PIX_SLOT)
   // k_shade's work: N_WORK_LISTS lists [build: FAST for 1..4 lights (3 forms), generic][frame % 8] of the tiles that have an owner, as
-  // {frame * tiles_per_frame + (lb*tiles_x + tx), V pixels | S pixels << 16}, in arrival order; work_cap entries each
-  uint2 *worklist;
+  // {frame * tiles_per_frame + (lb*tiles_x + tx), V pixels | S pixels << 11 | flags, list entries, list offset} (srz_kernels.hip,
+  // work_append), in arrival order; work_cap entries each
+  uint4 *worklist;
   uint32_t *work_count;          // [list * CNT_STRIDE]: word 0 = entries (zeroed by k_setup, bumped by k_raster), word 1 = k_shade's cursor
   uint32_t work_cap;
   uint32_t tiles_x, n_local_bands, n_frames;

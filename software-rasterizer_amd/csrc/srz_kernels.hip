@@ -1072,15 +1072,18 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
 // A tile that has an owner goes to one of 104 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
 // the same for frames with BUMP / DISPLACEMENT batches, the same for frames with a non-integer exponent, generic][frame % 8]
 // (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so every list comes
-// out (roughly) frame by frame.  An entry = {frame * tiles_per_frame + tile, V pixels | S pixels << 16}: the lengths of the tile's
-// two pixel lists travel with it.
-__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry, uint32_t counts) {
+// out (roughly) frame by frame.  An entry = {frame * tiles_per_frame + tile, V pixels | S pixels << 11 | WORK_LP, entries of the
+// tile's triangle list, its first index in pool[]}: everything k_shade needs to start the tile's loads travels with it.
+constexpr uint32_t WORK_CNT_BITS = 11, WORK_CNT_MASK = (1u << WORK_CNT_BITS) - 1u;
+constexpr uint32_t WORK_LP = 1u << 22; // the tile's pixel lists name their owners by POSITION in the tile's triangle list (see LP_BITS)
+__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry, uint32_t counts,
+                                            uint32_t list_cnt, uint32_t list_off) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
   const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
                             ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u) + ((frame_flags & FD_GENPOW) ? 8u : 0u)
                             : SHADE_KIND_GENERIC;
   const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
-  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint2(entry, counts);
+  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(entry, counts, list_cnt, list_off);
 }
 
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
@@ -1088,10 +1091,15 @@ constexpr uint32_t S_CLASS_BIT = 0x80000000u;
 
 // What the rasterisers hand to k_shade per OWNED tile: its visible pixels, already compacted by semantics class into two
 // lists in the tile's slot of `vis` (PIX_SLOT dwords): V pixels at [0, nV), S pixels at [nV, nV + nS), each list in row-major
-// pixel order, one entry = pixel (ly * 32 + lx, 10 bits) | owner triangle << 10.  k_shade starts a tile at its shading chunks:
-// no owner-id plane to load, classify and compact (that front end was a quarter of its wave time, DESIGN.md / NOTEBOOK.md).
-// Frames with 2^22 triangles or more (RenderArgs::wide_ids) store {pixel, owner} as two dwords per entry instead.
+// pixel order, one entry = pixel (ly * 32 + lx, 10 bits) | owner << 10.  k_shade starts a tile at its shading chunks:
+// no owner-id plane to load, classify and compact.
+// The owner is named by its POSITION in the tile's triangle list (k_raster, tiles of at most LP_MAX list entries in frames of
+// fewer than 2^22 - 1 triangles: the position rides in the low bits of the depth key's tie-break, below the triangle index, so
+// the pixel's final key holds it for free) — k_shade then stages the list's triangles in LDS once per tile and every pixel
+// reads its owner's 96 bytes from there instead of gathering them from memory — or by its index in the frame (the ordered
+// rasteriser, long lists).  Frames with 2^22 triangles or more (RenderArgs::wide_ids) store {pixel, index} dword pairs.
 constexpr uint32_t PIX_SLOT = TILE * TILE, PIX_BITS = 10, PIX_MASK = PIX_SLOT - 1u;
+constexpr uint32_t LP_BITS = 9, LP_MAX = 1u << LP_BITS, LP_TRIS = (1u << (31 - LP_BITS)) - 1u; // (idx << 9 | position) <= 0x7ffffffe
 // One strip of 8 rows x 32 pixels, 4 consecutive pixels per lane (lane → row lane / 8, columns (lane % 8) * 4 ..): the strip's
 // V | S << 16 pixel counts per lane and their inclusive wave scan
 __device__ __forceinline__ uint32_t strip_counts(const uint4 &id, uint32_t &incl) {
@@ -1135,24 +1143,44 @@ struct TriAttr {
   TriXY t;
   float n0x, n0y, n0z, n1x, n1y, n1z, n2x, n2y, n2z, u0, v0, u1, v1, u2, v2;
 };
-template <class M> __device__ __forceinline__ void unpack_tri(M &m, const TriFetch &f, TriAttr &a) {
-  // pos: q0.xyz q0.w q1.xy q1.zw q2.x | nrm: q2.yzw q3.xyz q3.w q4.xy | uv: q4.zw q5.xy q5.zw
+template <class M> __device__ __forceinline__ void unpack_pos(M &m, const TriFetch &f, TriAttr &a) {
+  // pos: q0.xyz q0.w q1.xy q1.zw q2.x
   a.t.ax = f.q0.x, a.t.ay = f.q0.y, a.t.z0 = f.q0.z, a.t.bx = f.q0.w, a.t.by = f.q1.x, a.t.z1 = f.q1.y, a.t.cx = f.q1.z,
   a.t.cy = f.q1.w, a.t.z2 = f.q2.x;
   tri_consts(m, a.t);
+}
+__device__ __forceinline__ void unpack_attr(const TriFetch &f, TriAttr &a) {
+  // nrm: q2.yzw q3.xyz q3.w q4.xy | uv: q4.zw q5.xy q5.zw
   a.n0x = f.q2.y, a.n0y = f.q2.z, a.n0z = f.q2.w, a.n1x = f.q3.x, a.n1y = f.q3.y, a.n1z = f.q3.z, a.n2x = f.q3.w, a.n2y = f.q4.x,
   a.n2z = f.q4.y;
   a.u0 = f.q4.z, a.v0 = f.q4.w, a.u1 = f.q5.x, a.v1 = f.q5.y, a.u2 = f.q5.z, a.v2 = f.q5.w;
 }
+// A triangle staged in LDS (k_shade, `late` != null) hands over its positions first and its normals / texture coordinates only
+// when the barycentrics exist: LDS is close, and 24 values fetched at once are 16 registers held for nothing (the dependency
+// on `dep` pins the second half of the reads behind the coverage arithmetic).  From memory (`late` == null) all 96 bytes come
+// in ONE round trip, up front.
+__device__ __forceinline__ void early_fetch(TriFetch &f, const f32x4 *late) {
+  if (late != nullptr) f.q0 = late[0], f.q1 = late[1], f.q2 = late[2];
+}
+__device__ __forceinline__ void late_fetch(TriFetch &f, const f32x4 *late, float dep) {
+  if (late != nullptr) {
+    asm volatile("" : "+v"(late) : "v"(dep));
+    f.q3 = late[3], f.q4 = late[4], f.q5 = late[5];
+  }
+}
 // Shade pixel (x,y) of depth z, owner `f`, 8-wide ("V") semantics (src/Rasterizer.cpp:380-389)
 template <class M, int SH = -1, int NL = 0>
-__device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
-                                              float &r0, float &r1, float &r2) {
+__device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f_in, const f32x4 *late, int x,
+                                              int y, float &r0, float &r1, float &r2) {
   TriAttr a;
-  unpack_tri(m, f, a);
+  TriFetch f = f_in; // (a local copy: what the staged reads below define must not outlive this call — the caller's loops would carry it)
+  early_fetch(f, late);
+  unpack_pos(m, f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
   cover_v(a.t, fx, fy, alpha, beta, gamma, zz);
+  late_fetch(f, late, gamma);
+  unpack_attr(f, a);
   float nx = fmaf_(alpha, a.n0x, fmaf_(beta, a.n1x, gamma * a.n2x));
   float ny = fmaf_(alpha, a.n0y, fmaf_(beta, a.n1y, gamma * a.n2y));
   float nz = fmaf_(alpha, a.n0z, fmaf_(beta, a.n1z, gamma * a.n2z));
@@ -1163,13 +1191,17 @@ __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const Shade
 }
 // scalar-tail ("S") semantics (src/Rasterizer.cpp:470-492)
 template <class M, int SH = -1, int NL = 0>
-__device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f, int x, int y,
-                                              float &r0, float &r1, float &r2) {
+__device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f_in, const f32x4 *late, int x,
+                                              int y, float &r0, float &r1, float &r2) {
   TriAttr a;
-  unpack_tri(m, f, a);
+  TriFetch f = f_in; // (a local copy: what the staged reads below define must not outlive this call — the caller's loops would carry it)
+  early_fetch(f, late);
+  unpack_pos(m, f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
   cover_s(a.t, fx, fy, alpha, beta, gamma, zz);
+  late_fetch(f, late, gamma);
+  unpack_attr(f, a);
   float nx = alpha * a.n0x + beta * a.n1x + gamma * a.n2x;
   float ny = alpha * a.n0y + beta * a.n1y + gamma * a.n2y;
   float nz = alpha * a.n0z + beta * a.n1z + gamma * a.n2z;
@@ -1199,11 +1231,11 @@ __global__ void probe_v(RenderArgs a, float *o) {
 #endif
 #ifdef SRZ_PROBE_S
   FastMath fm;
-  shade_pixel_s<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
+  shade_pixel_s<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, nullptr, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #else
   FastMath fm;
-  shade_pixel_v<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, threadIdx.x, blockIdx.x, r0, r1, r2);
+  shade_pixel_v<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, nullptr, threadIdx.x, blockIdx.x, r0, r1, r2);
   if (fm.bad) r0 = -1.f;
 #endif
   o[threadIdx.x] = r0 + r1 + r2;
@@ -1328,6 +1360,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     return;
   }
   const uint32_t off = tinfo.y;
+  // the tie-break's payload: the triangle's index, or index << LP_BITS | its position in this tile's list (same order)
+  const bool lp_mode = cnt <= LP_MAX && fd->n_tris < LP_TRIS && a.wide_ids == 0u; // wave-uniform
   if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
     if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
@@ -1429,7 +1463,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
   for (uint32_t base = 0; base < cnt; base += 64) {
     const f32x4 r0 = n0, r1 = n1, r2 = n2;
-    const uint32_t my_idx = i_cur;
+    const uint32_t my_idx = lp_mode ? ((i_cur << LP_BITS) | (base + (uint32_t)lane)) : i_cur; // (the tie-break's payload)
     // the per-triangle constants of the two coverage tests, once per record (a record carries 48 bytes, not these 8 more)
     float rec_v_inv, rec_s_area;
     {
@@ -1584,28 +1618,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   //  some final key needs the ordered algorithm  : the tile goes to k_raster_slow, nothing is written here
   //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
   //  owned tile          : z plane + the tile's two pixel lists, and the tile is queued for k_shade (which writes the 3 colour planes)
-  float4 z4[ITS];
-  uint4 id4[ITS];
+  // pass 1: what the whole tile must know before anything is written — does some final key need the ordered algorithm, does
+  // anybody own a pixel (the keys are read again below: two LDS reads per pixel cost less than 16 depths held in registers)
   bool any_owner = false, redo = false;
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
     const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const unsigned long long *kr = &s_key[ly * KEY_STRIDE + lx4]; // (rows are 264 bytes apart: 8-byte aligned reads)
-    const unsigned long long k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
-    const uint32_t tb[4] = {(uint32_t)k0, (uint32_t)k1, (uint32_t)k2, (uint32_t)k3};
-    const uint32_t zk[4] = {(uint32_t)(k0 >> 32), (uint32_t)(k1 >> 32), (uint32_t)(k2 >> 32), (uint32_t)(k3 >> 32)};
-    float zz[4];
-    uint32_t id[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      redo |= (zk[k] == 0u) | ((zk[k] + 0x80000001u) <= 1u); // NaN that passed / final depth ±0
-      zz[k] = z_of_key(zk[k]);
-      id[k] = (tb[k] & 0x80000000u) ? (tb[k] & 0x7fffffffu) : (tb[k] == TB_NONE ? NO_TRI : ((0x7ffffffeu - tb[k]) | S_CLASS_BIT));
-      any_owner |= tb[k] != TB_NONE;
+      const unsigned long long kk = kr[k];
+      const uint32_t zk = (uint32_t)(kk >> 32);
+      redo |= (zk == 0u) | ((zk + 0x80000001u) <= 1u); // NaN that passed / final depth ±0
+      any_owner |= (uint32_t)kk != TB_NONE;
     }
-    // (pixels of the tile beyond the frame's edge never got a fragment: their rectangles are clipped to tx1 / ty1)
-    z4[it] = make_float4(zz[0], zz[1], zz[2], zz[3]);
-    id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
   }
   bool tile_redo = __ballot(redo) != 0ull, tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
   if constexpr (WAVES > 1) { // tile-wide: through LDS
@@ -1618,38 +1644,54 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
   }
+  if (!tile_has_owner && !fused) return; // nothing of the framebuffer changes
+  // pass 2: strip by strip — the depths leave at once, the owners stay (16 registers) for the pixel lists
+  uint4 id4[ITS];
   const bool vec_ok = (W & 3) == 0;
-  if (tile_has_owner || fused) {
-    const size_t plane = (size_t)a.local_rows * (size_t)W;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t plane = (size_t)a.local_rows * (size_t)W;
 #pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
-      const int y = ty0 + ly, x4 = tx0 + lx4;
-      if (y > ty1 || x4 > tx1) continue;
-      float *gz = out0 + (size_t)ly * W + x4;
-      const bool full = vec_ok && x4 + 3 <= tx1;
-      if (tile_has_owner) {
-        if (full) {
-          store_nt(gz, z4[it]); // final: k_shade recomputes the depth it needs from the owner triangle
-        } else {
+  for (int it = 0; it < ITS; ++it) {
+    const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+    const unsigned long long *kr = &s_key[ly * KEY_STRIDE + lx4];
+    const unsigned long long k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
+    const uint32_t tb[4] = {(uint32_t)k0, (uint32_t)k1, (uint32_t)k2, (uint32_t)k3};
+    const float4 z4 = make_float4(z_of_key((uint32_t)(k0 >> 32)), z_of_key((uint32_t)(k1 >> 32)), z_of_key((uint32_t)(k2 >> 32)),
+                                  z_of_key((uint32_t)(k3 >> 32)));
+    uint32_t id[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // (what the pixel lists carry of the payload: the list position where the tie-breaks hold one, else the index;
+      // pixels of the tile beyond the frame's edge never got a fragment: their rectangles are clipped to tx1 / ty1)
+      const uint32_t pv = tb[k] & 0x7fffffffu, ps = 0x7ffffffeu - tb[k];
+      id[k] = (tb[k] & 0x80000000u) ? (lp_mode ? (pv & (LP_MAX - 1u)) : pv)
+                                    : (tb[k] == TB_NONE ? NO_TRI : ((lp_mode ? (ps & (LP_MAX - 1u)) : ps) | S_CLASS_BIT));
+    }
+    id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
+    const int y = ty0 + ly, x4 = tx0 + lx4;
+    if (y > ty1 || x4 > tx1) continue;
+    float *gz = out0 + (size_t)ly * W + x4;
+    const bool full = vec_ok && x4 + 3 <= tx1;
+    if (tile_has_owner) {
+      if (full) {
+        store_nt(gz, z4); // final: k_shade recomputes the depth it needs from the owner triangle
+      } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4[it].M;
-          SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+  if (x4 + K_ <= tx1) gz[K_] = z4.M;
+        SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
-        }
-      } else { // touched by a bbox but owned by nobody: the clear itself
-        if (full) {
-          store_nt(gz, z4[it]);
-          store_nt(gz + plane, zero4);
-          store_nt(gz + 2 * plane, zero4);
-          store_nt(gz + 3 * plane, zero4);
-        } else {
+      }
+    } else { // touched by a bbox but owned by nobody: the clear itself
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (full) {
+        store_nt(gz, z4);
+        store_nt(gz + plane, zero4);
+        store_nt(gz + 2 * plane, zero4);
+        store_nt(gz + 3 * plane, zero4);
+      } else {
 #define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
-          SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+  if (x4 + K_ <= tx1) gz[K_] = z4.M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
+        SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
 #undef SRZ_ST
-        }
       }
     }
   }
@@ -1710,7 +1752,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(stage + i);
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
-  if (lane == 0 && wave == 0) work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, nV | (nS << 16));
+  if (lane == 0 && wave == 0)
+    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, nV | (nS << WORK_CNT_BITS) | (lp_mode ? WORK_LP : 0u), cnt, off);
 }
 
 // ================================================================================================================
@@ -1937,7 +1980,7 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
       const uint32_t n_dw = (nV + nS) << (wide ? 1 : 0);
       uint32_t *dst = a.vis + (size_t)entry * ((size_t)PIX_SLOT << (wide ? 1 : 0));
       for (uint32_t i = (uint32_t)lane * 4u; i < n_dw; i += 256u) *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(stage + i);
-      if (lane == 0) work_append(a, fd->flags, frame, entry, nV | (nS << 16));
+      if (lane == 0) work_append(a, fd->flags, frame, entry, nV | (nS << WORK_CNT_BITS), 0u, 0u); // (owners by index)
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
@@ -1997,8 +2040,12 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 
 // k_shade is latency-sensitive: measurably slower at 3 waves per SIMD than at 4 — hold the allocator to 128 VGPRs
 #ifndef SRZ_FAST_MINW
-#define SRZ_FAST_MINW 5
+#define SRZ_FAST_MINW 6 // (80 VGPRs: the FAST builds for 1 / 2 lights fit with a few prologue spills; 3 lights keep 5 — see k_shade)
 #endif
+#ifndef SRZ_STAGE_TRIS
+#define SRZ_STAGE_TRIS 96 // triangles of a tile's list k_shade stages in LDS (12 KB colours + 4 KB lists + 9 KB triangles: 6 workgroups per CU)
+#endif
+constexpr uint32_t STAGE_TRIS = SRZ_STAGE_TRIS, STAGE_SD = 16;
 #ifndef SRZ_SHADE_MINW
 #define SRZ_SHADE_MINW 4
 #endif
@@ -2012,12 +2059,18 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 //   FASTNL < 0: the FAST build for -FASTNL lights and ANY exponent (pow_cr: ocml's binary64 pow for a non-integer one) — frames that
 //            differ from the common case only in Shader::p keep the per-chunk variants, the unrolled lights and the hoisted texel
 template <bool STATS, int FASTNL, bool BUMPY = false>
-__global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FAST_MINW : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
+__global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FAST_MINW : (FASTNL == 3 && !BUMPY) ? 5 : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
   constexpr bool FAST = FASTNL != 0, GENPOW = FASTNL < 0;
   static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
   static_assert(!(GENPOW && BUMPY), "frames with BUMP / DISPLACEMENT batches and a non-integer exponent take the generic build");
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_ent[PIX_SLOT];     // the tile's pixel lists (wide lists are read from global memory per chunk)
+  // the triangles of the tile's list, staged once per tile (96 bytes each, by list position) + their batch ids, and the frame's
+  // shader descriptors: a pixel takes its owner's data from here instead of gathering it from memory — 26 KB of LDS in all,
+  // six workgroups per CU as before
+  __shared__ __attribute__((aligned(16))) f32x4 s_tri[STAGE_TRIS * 6];
+  __shared__ uint16_t s_bat[STAGE_TRIS];
+  __shared__ __attribute__((aligned(16))) ShadeDescG s_sd[STAGE_SD];
   __shared__ uint32_t s_flag;                                           // "some operand left FastMath's range"
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2026,11 +2079,15 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
   const uint32_t tpf = a.n_local_bands * a.tiles_x;
   const bool wide = a.wide_ids != 0u; // wave-uniform
 
-  // ---- one owned tile: x = its work-list entry {frame * tiles_per_frame + tile, V pixels | S pixels << 16}.  mode: 0 = FAST
-  //      variants, 1 = generic (FastMath, then IEEE if needed), 2 = IEEE at once ------------------------------------------------
-  auto shade_tile = [&](const u32x2 x, auto mode_c) {
+  // ---- one owned tile: x = its work-list entry (work_append).  mode: 0 = FAST variants, 1 = generic (FastMath, then IEEE if
+  //      needed), 2 = IEEE at once -------------------------------------------------------------------------------------------------
+  auto shade_tile = [&](const u32x4 x, auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
-    const uint32_t nV = x.y & 0xffffu, nS = x.y >> 16;
+    const uint32_t nV = x.y & WORK_CNT_MASK, nS = (x.y >> WORK_CNT_BITS) & WORK_CNT_MASK;
+    // how the lists name a pixel's owner: by position in the tile's triangle list — the list's triangles are staged in LDS if they
+    // fit (by_lp && staged), else looked up per pixel (by_lp) — or by index in the frame
+    const bool by_lp = (x.y & WORK_LP) != 0u, staged = by_lp && x.z <= STAGE_TRIS; // workgroup-uniform
+    const SRZ_CAS uint32_t *tlist = as_const(a.pool) + x.w;
     // ---- 1. the tile's pixel lists (written by the rasteriser: V pixels, then S pixels, row-major each) → LDS, one coalesced
     //         load whose address needs nothing but the entry: it is in flight under the frame descriptor's scalar loads
     //         (issued here, parked in LDS only in front of the barrier below)
@@ -2048,6 +2105,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
     const SRZ_CAS srz_tri *tris = as_const(a.tris) + tri_off;
     const SRZ_CAS uint16_t *tri_batch = as_const(a.tri_batch) + tri_off;
     const SRZ_CAS ShadeDescG *sdesc = as_const(a.sdesc) + batch_off;
+    const bool sd_staged = fd->n_batches <= STAGE_SD; // workgroup-uniform
 
     const int band = (int)lb * a.shard_world + a.shard_rank;
     const int tx0 = (int)tx * TILE, ty0 = band * BAND;
@@ -2055,6 +2113,37 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     const size_t row0 = (size_t)lb * BAND;
     float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
+
+    // ---- 1b. the tile's triangles → LDS: 16-byte piece q of list entry l per thread (six threads per triangle, coalesced 96
+    //          bytes), the index loads of all of a thread's pieces in flight together, then the pieces themselves
+    if (staged) {
+      constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
+      const uint32_t n_pc = x.z * 6u;
+      uint32_t ti[PASSES];
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const uint32_t pc = (uint32_t)tid + 256u * k;
+        ti[k] = pc < n_pc ? tlist[pc / 6u] : 0u;
+      }
+      // (LDS-DMA: the 16-byte pieces go from memory straight to LDS — the wave's 64 pieces land one after the other at a
+      // wave-uniform base, which is s_tri's own order — and hold no registers while in flight; the barrier below drains them)
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const uint32_t pc = (uint32_t)tid + 256u * k;
+        if (pc < n_pc) {
+          const uint32_t q = pc % 6u;
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(a.tris + tri_off + ti[k]) + q,
+                                           (__attribute__((address_space(3))) void *)(s_tri + (wave * 64 + 256 * k)), 16, 0, 0);
+          if (q == 0u) s_bat[pc / 6u] = tri_batch[ti[k]];
+        }
+      }
+    }
+    if (sd_staged && (uint32_t)tid < fd->n_batches) {
+      const SRZ_CAS ShadeDescG *g = sdesc + tid;
+      ShadeDescG d;
+      d.shader = g->shader, d.tw = g->tw, d.th = g->th, d._pad = 0, d.tex = g->tex;
+      s_sd[tid] = d;
+    }
 
     // ---- 2. the colour staging planes start as what the pixels this call does not own must hold: 0 after the fused clear, else
     //         the colour already in the framebuffer (the z plane is not read: the shader's depth is recomputed from the owner
@@ -2089,9 +2178,9 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
     const uint32_t cV = (nV + 63) >> 6, cS = (nS + 63) >> 6;
     // (one loop per class: a single loop over both keeps the registers of the V and of the S shader alive together)
-    auto class_pass = [&](auto policy, auto is_v, bool count) -> bool {
+    auto class_pass = [&](auto policy, auto is_v, auto staged_c, bool count) -> bool {
       using M = decltype(policy);
-      constexpr bool isV = decltype(is_v)::value;
+      constexpr bool isV = decltype(is_v)::value, STAGED = decltype(staged_c)::value;
       bool bad = false;
       // the frame's shading constants are (re)read here, after the IO phase: scalar loads from a hot line, and ~20 SGPRs
       // fewer alive across the phase that has none to spare
@@ -2117,24 +2206,42 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
         float r0 = 1.f, r1 = 2.f, r2 = 3.f;
         ShadeDesc sd;
         TriFetch tf;
-        fetch_tri(tris, tri_batch, id, tf);
-        const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
-        sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+        const f32x4 *late = nullptr;
+        if constexpr (STAGED) { // the owner's positions and its batch from the tile's staged list now, its attributes later (late_fetch)
+          late = s_tri + id * 6u; // (read inside the shading variant: early_fetch / late_fetch)
+          tf.batch = s_bat[id];
+        } else {
+          if (by_lp) id = tlist[id]; // (a list too long for the stage: position → index, then the gather)
+          fetch_tri(tris, tri_batch, id, tf);
+        }
         const int px = tx0 + (int)(p & 31), py = ty0 + (int)(p >> 5);
         M m;
         if constexpr (MODE == 0) {
-          // one wave-uniform switch per chunk instead of per-pixel generality; a chunk that mixes shader types takes one
-          // pass per type (the lanes of the other types wait)
-          auto run = [&](auto sh) {
-            if constexpr (isV)
-              shade_pixel_v<M, decltype(sh)::value, FASTNL>(m, K, sd, tf, px, py, r0, r1, r2);
-            else
-              shade_pixel_s<M, decltype(sh)::value, FASTNL>(m, K, sd, tf, px, py, r0, r1, r2);
-          };
+          // The pixels of a chunk are shaded batch by batch (nearly always there is one): the batch's shader descriptor — type,
+          // texture size and address — is WAVE-UNIFORM (scalar registers: LDS read + readfirstlane, or scalar loads), one
+          // scalar switch picks the variant compiled for its shader type, and the lanes of other batches wait for their pass
           bool todo = true;
           for (unsigned long long tm = __ballot(true); tm != 0ull; tm = __ballot(todo)) {
-            const int sh0 = __builtin_amdgcn_readlane(sd.shader, __builtin_ctzll(tm)); // type of the first pixel still to do
-            if (todo && sd.shader == sh0) {
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)tf.batch, __builtin_ctzll(tm)); // batch of the first pixel still to do
+            if (sd_staged) {
+              const ShadeDescG &g = s_sd[b0];
+              const unsigned long long tp = reinterpret_cast<unsigned long long>(g.tex);
+              sd.shader = __builtin_amdgcn_readfirstlane(g.shader), sd.tw = __builtin_amdgcn_readfirstlane(g.tw);
+              sd.th = __builtin_amdgcn_readfirstlane(g.th);
+              sd.tex = reinterpret_cast<const SRZ_CAS uint32_t *>((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tp) |
+                                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tp >> 32)) << 32));
+            } else {
+              const SRZ_CAS ShadeDescG *g = sdesc + b0; // (uniform address: scalar loads)
+              sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+            }
+            if (todo && tf.batch == b0) {
+              auto run = [&](auto sh) {
+                if constexpr (isV)
+                  shade_pixel_v<M, decltype(sh)::value, FASTNL>(m, K, sd, tf, late, px, py, r0, r1, r2);
+                else
+                  shade_pixel_s<M, decltype(sh)::value, FASTNL>(m, K, sd, tf, late, px, py, r0, r1, r2);
+              };
+              const int sh0 = sd.shader; // wave-uniform
               if (sh0 == SRZ_SHADER_TEXTURE)
                 run(std::integral_constant<int, SRZ_SHADER_TEXTURE>{});
               else if (sh0 == SRZ_SHADER_PHONG)
@@ -2152,10 +2259,17 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
             }
           }
         } else {
+          if (sd_staged) {
+            const ShadeDescG &g = s_sd[tf.batch];
+            sd.shader = g.shader, sd.tw = g.tw, sd.th = g.th, sd.tex = as_const(g.tex);
+          } else {
+            const SRZ_CAS ShadeDescG *g = sdesc + tf.batch;
+            sd.shader = g->shader, sd.tw = g->tw, sd.th = g->th, sd.tex = as_const(g->tex);
+          }
           if constexpr (isV)
-            shade_pixel_v<M>(m, K, sd, tf, px, py, r0, r1, r2);
+            shade_pixel_v<M>(m, K, sd, tf, late, px, py, r0, r1, r2);
           else
-            shade_pixel_s<M>(m, K, sd, tf, px, py, r0, r1, r2);
+            shade_pixel_s<M>(m, K, sd, tf, late, px, py, r0, r1, r2);
         }
         if constexpr (std::is_same<M, FastMath>::value) bad |= m.bad;
         s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
@@ -2165,8 +2279,14 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
       return bad;
     };
     auto dense_passes = [&](auto policy, bool count) -> bool {
-      const bool bv = class_pass(policy, std::true_type{}, count);
-      const bool bs = class_pass(policy, std::false_type{}, count);
+      bool bv, bs;
+      if (staged) { // workgroup-uniform
+        bv = class_pass(policy, std::true_type{}, std::true_type{}, count);
+        bs = class_pass(policy, std::false_type{}, std::true_type{}, count);
+      } else {
+        bv = class_pass(policy, std::true_type{}, std::false_type{}, count);
+        bs = class_pass(policy, std::false_type{}, std::false_type{}, count);
+      }
       return bv | bs;
     };
     bool skip_write = false;
@@ -2182,7 +2302,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
       __syncthreads();
       if (s_flag) { // workgroup-uniform
         if constexpr (MODE == 0) { // hand the tile to the generic build
-          if (tid == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = make_uint2(x.x, x.y);
+          if (tid == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = make_uint4(x.x, x.y, x.z, x.w);
           skip_write = true;
         } else {
           if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
@@ -2220,14 +2340,14 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
   // persistent grid drawing tiles from atomic cursors the same on one stream but 7 % slower on two (it holds every CU slot to
   // its end), this walk 0.73 ms.
   const uint32_t L = (FAST ? (uint32_t)(light_count<FASTNL>() - 1) + (BUMPY ? 4u : 0u) + (GENPOW ? 8u : 0u) : SHADE_KIND_GENERIC) * 8u + (blockIdx.x & 7u);
-  const SRZ_CAS u32x2 *list = reinterpret_cast<const SRZ_CAS u32x2 *>(as_const(a.worklist)) + (size_t)L * a.work_cap;
+  const SRZ_CAS u32x4 *list = reinterpret_cast<const SRZ_CAS u32x4 *>(as_const(a.worklist)) + (size_t)L * a.work_cap;
   // the list's length and this workgroup's first entry are loaded TOGETHER (the entry's index is clamped into the list's
   // storage; it is used only if it lies below the length): one round trip instead of two before the tile's own loads start
   uint32_t w = blockIdx.x >> 3;
-  u32x2 x = list[min(w, a.work_cap - 1u)];
+  u32x4 x = list[min(w, a.work_cap - 1u)];
   const uint32_t n_work = (FAST || a.force_generic || a.any_generic) ? as_const(a.work_count)[L * CNT_STRIDE] : 0u;
   while (w < n_work) {
-    const u32x2 xc = x;
+    const u32x4 xc = x;
     w += gridDim.x >> 3;
     if (w < n_work) x = list[w];
     if constexpr (FAST)
@@ -2239,7 +2359,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 3 && !BUMPY) ? SRZ_FA
   if constexpr (!FAST) { // the tiles the FAST build handed back (it ran before this kernel on the same stream)
     const uint32_t n_redo = *as_const(a.redo_count);
     for (uint32_t i = blockIdx.x; i < n_redo; i += gridDim.x) {
-      const u32x2 xr = reinterpret_cast<const SRZ_CAS u32x2 *>(as_const(a.redo_list))[i];
+      const u32x4 xr = reinterpret_cast<const SRZ_CAS u32x4 *>(as_const(a.redo_list))[i];
       shade_tile(xr, std::integral_constant<int, 2>{});
       __syncthreads(); // LDS is reused by the next tile
     }
