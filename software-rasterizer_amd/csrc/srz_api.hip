@@ -58,7 +58,7 @@ struct srz_ctx {
   // diagnostic switches, read ONCE when the ctx is created (never per render): frames per sub-batch of a large set (0: the
   // default below), 32-bit owner ids even where 16 would do
   int env_sub_batch = 0;
-  bool env_wide_ids = false; // SRZ_WIDE_IDS (tests): two-dword pixel-list entries whatever the triangle count
+  bool env_no_packed = false; // SRZ_NO_PACKED (tests): see srz_frameset::no_packed
   bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
@@ -112,7 +112,7 @@ struct srz_frameset {
   bool any_generic = true;  // some frame needs the generic build
   uint32_t *d_vis = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr; // d_vis: the per-tile pixel lists (srz_device.h)
   uint4 *d_worklist = nullptr;
-  bool wide_ids = false; // some frame has >= 2^22 triangles: two dwords per pixel-list entry
+  bool no_packed = false; // SRZ_NO_PACKED (tests): no frame is FD_PACKED — 32-bit owner ids by triangle index, no staged triangles
   uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
   uint2 *d_band_ent = nullptr;     // and entries [group][ENT_PER_GROUP]
   uint64_t total_groups = 0;
@@ -184,8 +184,9 @@ void classify_frames(srz_frameset *fs) {
       bumpy = bumpy || sh == SRZ_SHADER_BUMP || sh == SRZ_SHADER_DISPLACEMENT;
     }
     const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && (intpow || !bumpy);
-    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | (7u << FD_NL_SHIFT))) |
-              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (intpow ? 0u : FD_GENPOW)) : 0u);
+    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | FD_PACKED | (7u << FD_NL_SHIFT))) |
+              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (intpow ? 0u : FD_GENPOW)) : 0u) |
+              ((d.n_tris < PACK_IDX_MASK && d.n_batches <= PACK_MAX_BATCHES && !fs->no_packed) ? FD_PACKED : 0u);
     if (fast)
       fs->fast_mask |= 1u << (d.n_lights + (bumpy ? 8u : 0u) + (intpow ? 0u : 16u));
     else
@@ -252,7 +253,6 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.force_ordered = 0, a.force_generic = 0, a.any_generic = fs->any_generic ? 1u : 0u;
   a.sdesc = fs->d_sdesc;
   a.vis = fs->d_vis;
-  a.wide_ids = fs->wide_ids ? 1u : 0u;
   a.worklist = fs->d_worklist;
   a.work_count = fs->d_work_count;
   // (a list holds the tiles of every 8th frame; of fewer than 8 frames: any of them)
@@ -429,7 +429,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     const int n = std::min(chunk, n_all - f0);
     if (n != n_all) {
       v.frames += f0, v.n_frames = (uint32_t)n;
-      v.vis += (size_t)f0 * tpf * ((size_t)TILE * TILE << (fs->wide_ids ? 1 : 0));
+      v.vis += (size_t)f0 * tpf * ((size_t)TILE * TILE);
       v.tile_info += (size_t)f0 * tpf;
       v.out += (size_t)f0 * a.frame_stride;
       v.work_cap = (uint32_t)((size_t)(n < 8 ? n : (n + 7) / 8) * tpf);
@@ -558,7 +558,7 @@ int srz_create(srz_ctx **out, int device_id) {
   if (!ctx) return fail(nullptr, SRZ_E_NOMEM, "srz_create: out of host memory");
   ctx->device = device_id;
   ctx->env_sub_batch = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0;
-  ctx->env_wide_ids = getenv("SRZ_WIDE_IDS") != nullptr;
+  ctx->env_no_packed = getenv("SRZ_NO_PACKED") != nullptr;
   ctx->opt_pool_lazy = getenv("SRZ_POOL_LAZY") != nullptr;
   for (int i = 0; i < MAX_TEX; ++i) ctx->h_tex[i] = TexDesc{nullptr, 0, 0}, ctx->d_texmem[i] = nullptr;
   auto bail = [&](const char *what, hipError_t err) {
@@ -707,6 +707,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     tri_off += nt, light_off += fr.n_lights, batch_off += fr.n_batches;
   }
   fs->total_tris = tri_off, fs->total_lights = light_off, fs->total_groups = group_off;
+  fs->no_packed = ctx->env_no_packed;
   fs->pool_sized = ctx->opt_pool_lazy; // (SRZ_OPT_POOL_LAZY: no first-render sizing — the pool only follows the previous renders' demand)
   classify_frames(fs);
 
@@ -760,8 +761,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     FS_TRY(dev_alloc((void **)&fs->d_slow_count, 2 * sizeof(uint32_t)));
     FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint4) * fs->max_tiles));
   }
-  fs->wide_ids = ctx->env_wide_ids || fs->max_tris >= (1u << 22);
-  FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)fs->max_tiles * ((size_t)TILE * TILE << (fs->wide_ids ? 1 : 0))));
+  FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)fs->max_tiles * ((size_t)TILE * TILE)));
   FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint4) * N_WORK_LISTS * (size_t)(n_frames < 8 ? n_frames : (n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x));
   FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * CNT_STRIDE * N_WORK_LISTS));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));

@@ -24,6 +24,10 @@ constexpr uint32_t CNT_STRIDE = 32;
 // FrameDesc::flags, internal (set by the host): 1..4 lights and an integer exponent 0..256 → the FAST build of k_shade for that count
 constexpr uint32_t FD_FAST_SHADE = 0x100u, FD_NL_SHIFT = 9; // (+ the light count 1..4 in bits 9..11)
 constexpr uint32_t FD_BUMPY = 0x1000u;                   // some batch of the frame is BUMP / DISPLACEMENT (FAST builds with those variants)
+constexpr uint32_t FD_PACKED = 0x4000u;                  // fewer than 2^22 - 1 triangles and at most 1024 batches: a tile-list entry is
+                                                         // triangle index | batch << 22 (k_shade stages the tile's triangles without
+                                                         // a gather of their batch ids), and the depth keys' tie-breaks carry list positions
+constexpr uint32_t PACK_IDX_BITS = 22, PACK_IDX_MASK = (1u << PACK_IDX_BITS) - 1u, PACK_MAX_BATCHES = 1024;
 constexpr uint32_t FD_GENPOW = 0x2000u;                  // the exponent is not an integer 0..256: FAST builds whose power is pow_cr (ocml pow in binary64)
 constexpr uint32_t SHADE_KIND_GENERIC = 12;              // k_shade builds: kinds 0..3 = FAST for 1..4 lights, 4..7 = the same + BUMPY,
                                                          // 8..11 = FAST for 1..4 lights with any exponent (GENPOW), 12 = generic
@@ -142,13 +146,12 @@ struct RenderArgs {
   uint32_t any_generic;          // some frame is not FD_FAST_SHADE (else the generic build only serves redo_list)
   uint4 *redo_list;              // work-list entries of the tiles the FAST builds of k_shade hand to the generic one
   uint32_t *redo_count;
-  uint32_t wide_ids;             // some frame of the set has >= 2^22 triangles: the pixel lists hold {pixel, owner} dword pairs
-  uint32_t *vis;                 // per-tile pixel lists [frame][local band][tile x][PIX_SLOT (x 2 if wide_ids) dwords]: the visible
-                                 // pixels of an owned tile by class — V entries, then S entries; pixel | owner << 10 — written by the
-                                 // rasterisers' write-out, read by k_shade (srz_kernels.hip, PIX_SLOT)
+  uint32_t *vis;                 // owner ids per tile [frame][local band][tile x][PIX_SLOT dwords]: 16 bits per pixel (position in
+                                 // the tile's triangle list) or 32 (index in the frame) — written by the rasterisers' write-out for
+                                 // tiles that have an owner, read by k_shade (srz_kernels.hip, PIX_SLOT)
   // k_shade's work: N_WORK_LISTS lists [build: FAST for 1..4 lights (3 forms), generic][frame % 8] of the tiles that have an owner, as
-  // {frame * tiles_per_frame + (lb*tiles_x + tx), V pixels | S pixels << 11 | flags, list entries, list offset} (srz_kernels.hip,
-  // work_append), in arrival order; work_cap entries each
+  // {frame * tiles_per_frame + (lb*tiles_x + tx), flags, list entries, list offset} (srz_kernels.hip, work_append), in arrival
+  // order; work_cap entries each
   uint4 *worklist;
   uint32_t *work_count;          // [list * CNT_STRIDE]: word 0 = entries (zeroed by k_setup, bumped by k_raster), word 1 = k_shade's cursor
   uint32_t work_cap;

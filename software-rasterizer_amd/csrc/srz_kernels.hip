@@ -462,8 +462,9 @@ __device__ __forceinline__ void clip_range(int &i0, int &i1, float mn, float mx,
 // DESC_RAW in every band instead: k_bin's band workgroups then walk its bounding boxes themselves.
 // ================================================================================================================
 __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t nlb, const uint32_t group, const uint32_t t0,
-                                             const BBox (&bb)[GROUP_K], const bool (&keep)[GROUP_K], const float (*P)[9],
-                                             uint32_t *s_cnt, uint32_t *s_off, uint32_t *s_fill, uint32_t *s_misc) {
+                                             const bool packed, const uint32_t tri_off, const BBox (&bb)[GROUP_K],
+                                             const bool (&keep)[GROUP_K], const float (*P)[9], uint32_t *s_cnt, uint32_t *s_off,
+                                             uint32_t *s_fill, uint32_t *s_misc) {
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int world = a.shard_world, rank = a.shard_rank;
   for (uint32_t i = (uint32_t)tid; i < nlb; i += 256u) s_cnt[i] = 0u;
@@ -494,6 +495,15 @@ __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t
   }
   __syncthreads();
   const bool raw = s_misc[0] != 0u;
+  // what a tile list holds of a triangle: its index in the frame — and, FD_PACKED, its batch above it (coalesced 2-byte loads here,
+  // instead of a gather per staged triangle in k_shade)
+  uint32_t tpk[GROUP_K];
+#pragma unroll
+  for (int k = 0; k < (int)GROUP_K; ++k) {
+    const uint32_t t = t0 + (uint32_t)k * 256u + (uint32_t)tid;
+    tpk[k] = t;
+    if (packed && keep[k]) tpk[k] = t | ((uint32_t)as_const(a.tri_batch)[tri_off + t] << PACK_IDX_BITS);
+  }
   uint32_t *desc = a.band_desc + (size_t)group * nlb;
   for (uint32_t i = (uint32_t)tid; i < nlb; i += 256u) desc[i] = raw ? DESC_RAW : ((s_off[i] << 16) | s_cnt[i]);
   if (!raw) {
@@ -519,7 +529,7 @@ __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t
           clip_range(X0, X1, mn, mx, m);
           xr_j = X0 <= X1 ? ((uint32_t)(X0 >> 5) | ((uint32_t)(X1 >> 5) << 16)) : 1u; // (1: tiles 1 .. 0 = none)
         }
-        ent[atomicAdd(&s_fill[lb0[k] + j], 1u)] = make_uint2(t0 + (uint32_t)k * 256u + (uint32_t)tid, xr_j);
+        ent[atomicAdd(&s_fill[lb0[k] + j], 1u)] = make_uint2(tpk[k], xr_j);
       }
     }
   }
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
       if (keep[k]) prep_store(a.prep + tri_off + t, P[k], bb[k]);
       chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
     }
-    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, P, s_cnt, s_off, s_fill, s_misc);
+    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, (fd->flags & FD_PACKED) != 0u, tri_off, bb, keep, P, s_cnt, s_off, s_fill, s_misc);
   }
   if (STATS) {
     if (n_culled) atomicAdd(&a.stats[ST_CULLED], n_culled);
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
       keep[k] = bb[k].sx <= bb[k].ex; // (the empty box of a culled triangle: sx > ex)
       chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
     }
-    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, bb, keep, nullptr, s_cnt, s_off, s_fill, s_misc);
+    bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, (fd->flags & FD_PACKED) != 0u, tri_off, bb, keep, nullptr, s_cnt, s_off, s_fill, s_misc);
   }
 }
 
@@ -661,6 +671,7 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   s_mark[lane] = 0u;
   __syncthreads();
   const uint32_t n_tris = fd->n_tris;
+  const bool packed = (fd->flags & FD_PACKED) != 0u; // (tile-list entries carry the batch above the index)
   const int band = (int)lb * a.shard_world + a.shard_rank;
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
   const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
@@ -698,7 +709,10 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
         if (!ok[u]) break; // wave-uniform
         const uint32_t t = (c0 + cj[u]) * 64u + (uint32_t)lane;
         const int sx = (int16_t)(r[u].x & 0xffff), sy = (int16_t)(r[u].x >> 16), ex = (int16_t)(r[u].y & 0xffff), ey = (int16_t)(r[u].y >> 16);
-        fn(t, t < n_tris && sx <= ex && sy <= y1 && ey >= y0, sx >> 5, ex >> 5); // (bbox is clamped to the frame by k_setup)
+        const bool hit = t < n_tris && sx <= ex && sy <= y1 && ey >= y0; // (bbox is clamped to the frame by k_setup)
+        uint32_t tp = t;
+        if (packed && hit) tp |= (uint32_t)as_const(a.tri_batch)[fd->tri_off + t] << PACK_IDX_BITS;
+        fn(tp, hit, sx >> 5, ex >> 5);
       }
     }
   };
@@ -1072,59 +1086,50 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
 // A tile that has an owner goes to one of 104 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
 // the same for frames with BUMP / DISPLACEMENT batches, the same for frames with a non-integer exponent, generic][frame % 8]
 // (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so every list comes
-// out (roughly) frame by frame.  An entry = {frame * tiles_per_frame + tile, V pixels | S pixels << 11 | WORK_LP, entries of the
-// tile's triangle list, its first index in pool[]}: everything k_shade needs to start the tile's loads travels with it.
-constexpr uint32_t WORK_CNT_BITS = 11, WORK_CNT_MASK = (1u << WORK_CNT_BITS) - 1u;
-constexpr uint32_t WORK_LP = 1u << 22; // the tile's pixel lists name their owners by POSITION in the tile's triangle list (see LP_BITS)
-__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry, uint32_t counts,
+// out (roughly) frame by frame.  An entry = {frame * tiles_per_frame + tile, flags (WORK_LP), entries of the tile's triangle
+// list, its first index in pool[]}: everything k_shade needs to start the tile's loads travels with it.
+constexpr uint32_t WORK_LP = 1u; // the tile's owner ids are POSITIONS in the tile's triangle list, 16 bits each (see LP_BITS)
+__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry, uint32_t wflags,
                                             uint32_t list_cnt, uint32_t list_off) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
   const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
                             ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u) + ((frame_flags & FD_GENPOW) ? 8u : 0u)
                             : SHADE_KIND_GENERIC;
   const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
-  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(entry, counts, list_cnt, list_off);
+  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(entry, wflags, list_cnt, list_off);
 }
 
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
 constexpr uint32_t S_CLASS_BIT = 0x80000000u;
 
-// What the rasterisers hand to k_shade per OWNED tile: its visible pixels, already compacted by semantics class into two
-// lists in the tile's slot of `vis` (PIX_SLOT dwords): V pixels at [0, nV), S pixels at [nV, nV + nS), each list in row-major
-// pixel order, one entry = pixel (ly * 32 + lx, 10 bits) | owner << 10.  k_shade starts a tile at its shading chunks:
-// no owner-id plane to load, classify and compact.
-// The owner is named by its POSITION in the tile's triangle list (k_raster, tiles of at most LP_MAX list entries in frames of
-// fewer than 2^22 - 1 triangles: the position rides in the low bits of the depth key's tie-break, below the triangle index, so
-// the pixel's final key holds it for free) — k_shade then stages the list's triangles in LDS once per tile and every pixel
-// reads its owner's 96 bytes from there instead of gathering them from memory — or by its index in the frame (the ordered
-// rasteriser, long lists).  Frames with 2^22 triangles or more (RenderArgs::wide_ids) store {pixel, index} dword pairs.
+// What the rasterisers hand to k_shade per OWNED tile: the owner of every pixel, in the tile's slot of `vis` (PIX_SLOT dwords,
+// pixel p = ly * 32 + lx).  The owner is named
+//   by its POSITION in the tile's triangle list, 16 bits per pixel (position | 0x8000 for the S class, 0xffff = nobody) — k_raster,
+//      tiles of at most LP_MAX list entries in frames of fewer than 2^22 - 1 triangles: the position rides in the low bits of the
+//      depth key's tie-break, below the triangle index, so the pixel's final key holds it for free (work entry flag WORK_LP).
+//      k_shade then stages the list's triangles in LDS once per tile and every pixel reads its owner's 96 bytes from there
+//      instead of gathering them from memory; and a frame of 94 k triangles pays 2 bytes per pixel like one of 5 k;
+//   or by its index in the frame, 32 bits per pixel (index | S_CLASS_BIT, NO_TRI = nobody) — the ordered rasteriser, long lists.
 constexpr uint32_t PIX_SLOT = TILE * TILE, PIX_BITS = 10, PIX_MASK = PIX_SLOT - 1u;
-constexpr uint32_t LP_BITS = 9, LP_MAX = 1u << LP_BITS, LP_TRIS = (1u << (31 - LP_BITS)) - 1u; // (idx << 9 | position) <= 0x7ffffffe
-// One strip of 8 rows x 32 pixels, 4 consecutive pixels per lane (lane → row lane / 8, columns (lane % 8) * 4 ..): the strip's
-// V | S << 16 pixel counts per lane and their inclusive wave scan
-__device__ __forceinline__ uint32_t strip_counts(const uint4 &id, uint32_t &incl) {
-  const uint32_t k[4] = {id.x, id.y, id.z, id.w};
-  uint32_t c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c += k[j] == NO_TRI ? 0u : ((k[j] & S_CLASS_BIT) ? 0x10000u : 1u);
-  incl = wave_scan_add(c);
-  return c;
-}
-// the lane's entries of one strip into the LDS stage: V from oV on, S from oS on (both already include the lists' bases).
-// Branch-free: a pixel nobody owns stores to the dummy slot `dump` (behind the lists: entry PIX_SLOT + lane)
-template <bool WIDE>
-__device__ __forceinline__ void strip_scatter(uint32_t *stage, const uint4 &id, uint32_t p0, uint32_t oV, uint32_t oS, uint32_t dump) {
-  const uint32_t k[4] = {id.x, id.y, id.z, id.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool own = k[j] != NO_TRI, isS = (int32_t)k[j] < 0 && own; // (NO_TRI has bit 31 set too)
-    const uint32_t o = own ? (isS ? oS : oV) : dump;
-    if (WIDE)
-      *reinterpret_cast<u32x2 *>(stage + 2 * o) = u32x2{p0 + (uint32_t)j, k[j] & ~S_CLASS_BIT};
-    else
-      stage[o] = (p0 + (uint32_t)j) | (k[j] << PIX_BITS); // (the class bit is shifted out)
-    oV += (own && !isS) ? 1u : 0u, oS += isS ? 1u : 0u;
+constexpr uint32_t LP_BITS = 9, LP_MAX = 1u << LP_BITS; // (idx << 9 | position) <= 0x7ffffffe for idx < 2^22 - 1 (FD_PACKED)
+static_assert(31 - LP_BITS == PACK_IDX_BITS, "the tie-break holds an index of PACK_IDX_BITS bits above the list position");
+__device__ __forceinline__ uint32_t id_pack16(uint32_t id) { return id == NO_TRI ? 0xffffu : ((id & (LP_MAX - 1u)) | ((id >> 16) & 0x8000u)); }
+__device__ __forceinline__ uint32_t id_unpack16(uint32_t h) { return h == 0xffffu ? NO_TRI : ((h & (LP_MAX - 1u)) | ((h & 0x8000u) << 16)); }
+// the four owners of pixels p0 .. p0 + 3 of a tile (p0 % 4 == 0) into / out of its slot
+__device__ __forceinline__ void ids_store4(uint32_t *slot, uint32_t p0, const uint4 &id, bool by_lp) {
+  if (by_lp) {
+    const u32x2 w = {id_pack16(id.x) | (id_pack16(id.y) << 16), id_pack16(id.z) | (id_pack16(id.w) << 16)};
+    *reinterpret_cast<u32x2 *>(reinterpret_cast<uint16_t *>(slot) + p0) = w;
+  } else {
+    *reinterpret_cast<uint4 *>(slot + p0) = id;
   }
+}
+__device__ __forceinline__ uint4 ids_load4(const uint32_t *slot, uint32_t p0, bool by_lp) {
+  if (by_lp) {
+    const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint16_t *>(slot) + p0);
+    return make_uint4(id_unpack16(w.x & 0xffffu), id_unpack16(w.x >> 16), id_unpack16(w.y & 0xffffu), id_unpack16(w.y >> 16));
+  }
+  return *reinterpret_cast<const uint4 *>(slot + p0);
 }
 
 // Everything the shader needs about the owner triangle of one pixel, fetched in ONE round trip (7 independent loads)
@@ -1361,7 +1366,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   }
   const uint32_t off = tinfo.y;
   // the tie-break's payload: the triangle's index, or index << LP_BITS | its position in this tile's list (same order)
-  const bool lp_mode = cnt <= LP_MAX && fd->n_tris < LP_TRIS && a.wide_ids == 0u; // wave-uniform
+  const bool lp_mode = cnt <= LP_MAX && (fd->flags & FD_PACKED) != 0u; // wave-uniform
+  const uint32_t idx_mask = (fd->flags & FD_PACKED) ? PACK_IDX_MASK : 0xffffffffu; // (a packed list entry = index | batch << 22)
   if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
     if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
@@ -1377,7 +1383,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   float *out0 = a.out + (size_t)frame * a.frame_stride + row0 * (size_t)W; // plane 0 (z), row ty0
 
   // (the first 64 indices of the tile's list are loaded under the tile init)
-  const uint32_t i_first = as_const(a.pool)[off + min((uint32_t)lane, cnt - 1u)];
+  const uint32_t i_first = as_const(a.pool)[off + min((uint32_t)lane, cnt - 1u)] & idx_mask;
   // ---- phase A: tile init (fused clear → +inf, else the in/out z plane) with the incoming-depth tie-break ----------
   if (fused) { // (wave-uniform) straight stores of one constant: nothing here waits for the index load above
     const unsigned long long k_inf = ((unsigned long long)zkey_of(__builtin_inff()) << 32) | TB_NONE;
@@ -1459,7 +1465,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   // two-deep pipeline: the indices of chunk c + 2 and the records of chunk c + 1 are in flight while chunk c is rasterised
   f32x4 n0, n1, n2;
   bool nv = (uint32_t)lane < cnt;
-  uint32_t i_cur = i_first, i_nxt = 64u < cnt ? list[min(64u + (uint32_t)lane, cnt - 1u)] : 0u;
+  uint32_t i_cur = i_first, i_nxt = 64u < cnt ? (list[min(64u + (uint32_t)lane, cnt - 1u)] & idx_mask) : 0u;
   n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
   for (uint32_t base = 0; base < cnt; base += 64) {
     const f32x4 r0 = n0, r1 = n1, r2 = n2;
@@ -1478,7 +1484,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     if (base + 64 < cnt) {
       i_cur = i_nxt;
       n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
-      if (base + 128 < cnt) i_nxt = list[min(base + 128u + (uint32_t)lane, cnt - 1u)];
+      if (base + 128 < cnt) i_nxt = list[min(base + 128u + (uint32_t)lane, cnt - 1u)] & idx_mask;
     }
     const Geo G = geometry(r0, r1, r2, rec_s_area, valid);
     const uint32_t geom = G.word;
@@ -1617,21 +1623,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   // ---- phase C: decode the keys, write out ------------------------------------------------------------------------
   //  some final key needs the ordered algorithm  : the tile goes to k_raster_slow, nothing is written here
   //  nobody owns the tile: fused → the clear itself (z=+inf, colour 0), else the framebuffer is left untouched
-  //  owned tile          : z plane + the tile's two pixel lists, and the tile is queued for k_shade (which writes the 3 colour planes)
-  // pass 1: what the whole tile must know before anything is written — does some final key need the ordered algorithm, does
-  // anybody own a pixel (the keys are read again below: two LDS reads per pixel cost less than 16 depths held in registers)
+  //  owned tile          : z plane + owner ids, and the tile is queued for k_shade (which writes the 3 colour planes)
+  float4 z4[ITS];
+  uint4 id4[ITS];
   bool any_owner = false, redo = false;
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
     const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const unsigned long long *kr = &s_key[ly * KEY_STRIDE + lx4]; // (rows are 264 bytes apart: 8-byte aligned reads)
+    const unsigned long long k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
+    const uint32_t tb[4] = {(uint32_t)k0, (uint32_t)k1, (uint32_t)k2, (uint32_t)k3};
+    const uint32_t zk[4] = {(uint32_t)(k0 >> 32), (uint32_t)(k1 >> 32), (uint32_t)(k2 >> 32), (uint32_t)(k3 >> 32)};
+    float zz[4];
+    uint32_t id[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const unsigned long long kk = kr[k];
-      const uint32_t zk = (uint32_t)(kk >> 32);
-      redo |= (zk == 0u) | ((zk + 0x80000001u) <= 1u); // NaN that passed / final depth ±0
-      any_owner |= (uint32_t)kk != TB_NONE;
+      redo |= (zk[k] == 0u) | ((zk[k] + 0x80000001u) <= 1u); // NaN that passed / final depth ±0
+      zz[k] = z_of_key(zk[k]);
+      // (the payload of the tie-break: the triangle's index, or — lp_mode — index << LP_BITS | list position: the ids keep
+      // either all of it or its position bits, id_pack16)
+      id[k] = (tb[k] & 0x80000000u) ? (tb[k] & 0x7fffffffu) : (tb[k] == TB_NONE ? NO_TRI : ((0x7ffffffeu - tb[k]) | S_CLASS_BIT));
+      any_owner |= tb[k] != TB_NONE;
     }
+    z4[it] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+    id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
   }
   bool tile_redo = __ballot(redo) != 0ull, tile_has_owner = __ballot(any_owner) != 0ull; // wave-uniform
   if constexpr (WAVES > 1) { // tile-wide: through LDS
@@ -1644,116 +1659,48 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
     return;
   }
-  if (!tile_has_owner && !fused) return; // nothing of the framebuffer changes
-  // pass 2: strip by strip — the depths leave at once, the owners stay (16 registers) for the pixel lists
-  uint4 id4[ITS];
   const bool vec_ok = (W & 3) == 0;
-  const size_t plane = (size_t)a.local_rows * (size_t)W;
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
-    const unsigned long long *kr = &s_key[ly * KEY_STRIDE + lx4];
-    const unsigned long long k0 = kr[0], k1 = kr[1], k2 = kr[2], k3 = kr[3];
-    const uint32_t tb[4] = {(uint32_t)k0, (uint32_t)k1, (uint32_t)k2, (uint32_t)k3};
-    const float4 z4 = make_float4(z_of_key((uint32_t)(k0 >> 32)), z_of_key((uint32_t)(k1 >> 32)), z_of_key((uint32_t)(k2 >> 32)),
-                                  z_of_key((uint32_t)(k3 >> 32)));
-    uint32_t id[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // (what the pixel lists carry of the payload: the list position where the tie-breaks hold one, else the index;
-      // pixels of the tile beyond the frame's edge never got a fragment: their rectangles are clipped to tx1 / ty1)
-      const uint32_t pv = tb[k] & 0x7fffffffu, ps = 0x7ffffffeu - tb[k];
-      id[k] = (tb[k] & 0x80000000u) ? (lp_mode ? (pv & (LP_MAX - 1u)) : pv)
-                                    : (tb[k] == TB_NONE ? NO_TRI : ((lp_mode ? (ps & (LP_MAX - 1u)) : ps) | S_CLASS_BIT));
-    }
-    id4[it] = make_uint4(id[0], id[1], id[2], id[3]);
-    const int y = ty0 + ly, x4 = tx0 + lx4;
-    if (y > ty1 || x4 > tx1) continue;
-    float *gz = out0 + (size_t)ly * W + x4;
-    const bool full = vec_ok && x4 + 3 <= tx1;
-    if (tile_has_owner) {
-      if (full) {
-        store_nt(gz, z4); // final: k_shade recomputes the depth it needs from the owner triangle
-      } else {
-#define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4.M;
-        SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
-#undef SRZ_ST
-      }
-    } else { // touched by a bbox but owned by nobody: the clear itself
-      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (full) {
-        store_nt(gz, z4);
-        store_nt(gz + plane, zero4);
-        store_nt(gz + 2 * plane, zero4);
-        store_nt(gz + 3 * plane, zero4);
-      } else {
-#define SRZ_ST(K_, M)                                                                                                  \
-  if (x4 + K_ <= tx1) gz[K_] = z4.M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
-        SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
-#undef SRZ_ST
-      }
-    }
-  }
-  if (!tile_has_owner) return; // workgroup-uniform
-  // ---- the tile's visible pixels, compacted by class: V list, then S list (see PIX_SLOT) -----------------------------------
-  // every pixel's owner is in registers (id4): per 8-row strip a packed count + DPP scan, the entries assembled in the dead
-  // keys' LDS and stored as ONE coalesced run of 16-byte stores (cacheable: k_shade reads them back)
-  uint32_t cnt2[ITS], incl2[ITS], baseV[ITS], baseS[ITS], nV = 0, nS = 0;
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) cnt2[it] = strip_counts(id4[it], incl2[it]);
-  if constexpr (WAVES > 1) { // (one strip per wave: the strips' totals through LDS)
-    if (lane == 63) s_mark_x[wave] = incl2[0];
-    __syncthreads(); // (also: every wave has read its keys — the stage below overwrites them)
-    uint32_t bv = 0, bs = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < WAVES; ++w2) {
-      const uint32_t t2 = s_mark_x[w2];
-      bv += w2 < wave ? (t2 & 0xffffu) : 0u, bs += w2 < wave ? (t2 >> 16) : 0u, nV += t2 & 0xffffu, nS += t2 >> 16;
-    }
-    baseV[0] = bv, baseS[0] = bs;
-  } else {
+  if (tile_has_owner || fused) {
+    const size_t plane = (size_t)a.local_rows * (size_t)W;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t *slot = a.vis + ((size_t)frame * tiles_per_frame + tile) * PIX_SLOT;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-      const uint32_t t2 = (uint32_t)rl_i((int)incl2[it], 63);
-      baseV[it] = nV, baseS[it] = nS, nV += t2 & 0xffffu, nS += t2 >> 16;
+      const int ly = (wave * ITS + it) * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+      const int y = ty0 + ly, x4 = tx0 + lx4;
+      // the owners of ALL of the tile's pixels (those beyond the frame's edge have none: their keys never got a fragment);
+      // re-read by k_shade: cacheable
+      if (tile_has_owner) ids_store4(slot, (uint32_t)(ly * TILE + lx4), id4[it], lp_mode);
+      if (y > ty1 || x4 > tx1) continue;
+      float *gz = out0 + (size_t)ly * W + x4;
+      const bool full = vec_ok && x4 + 3 <= tx1;
+      if (tile_has_owner) {
+        if (full) {
+          store_nt(gz, z4[it]); // final: k_shade recomputes the depth it needs from the owner triangle
+        } else {
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[K_] = z4[it].M;
+          SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+#undef SRZ_ST
+        }
+      } else { // touched by a bbox but owned by nobody: the clear itself
+        if (full) {
+          store_nt(gz, z4[it]);
+          store_nt(gz + plane, zero4);
+          store_nt(gz + 2 * plane, zero4);
+          store_nt(gz + 3 * plane, zero4);
+        } else {
+#define SRZ_ST(K_, M)                                                                                                  \
+  if (x4 + K_ <= tx1) gz[K_] = z4[it].M, gz[plane + K_] = 0.f, gz[2 * plane + K_] = 0.f, gz[3 * plane + K_] = 0.f;
+          SRZ_ST(0, x) SRZ_ST(1, y) SRZ_ST(2, z) SRZ_ST(3, w)
+#undef SRZ_ST
+        }
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the key reads above stay in front of the stage's stores)
-    __builtin_amdgcn_wave_barrier();
-  }
-  uint32_t *const stage = reinterpret_cast<uint32_t *>(s_key);
-  const bool wide = a.wide_ids != 0u; // wave-uniform
-  static_assert(sizeof(s_key) >= 2 * (PIX_SLOT + 32) * 4 && sizeof(s_key) >= (PIX_SLOT + 64 * WAVES) * 4, "the stage holds the lists and the dummy slots");
-  auto scatter_all = [&](auto wide_c) {
-    constexpr bool WIDE = decltype(wide_c)::value;
-    // dummy slots for the pixels nobody owns: the entries behind the lists (the keys' block is 2112 dwords: 1088 more narrow
-    // entries, or 32 wide ones which the lanes share — nobody reads a dummy)
-    const uint32_t dump = WIDE ? (PIX_SLOT + ((uint32_t)threadIdx.x & 31u)) : (PIX_SLOT + (uint32_t)threadIdx.x);
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const uint32_t p0 = (uint32_t)(((wave * ITS + it) * 8 + (lane >> 3)) * TILE + (lane & 7) * 4), ex = incl2[it] - cnt2[it];
-      strip_scatter<WIDE>(stage, id4[it], p0, baseV[it] + (ex & 0xffffu), nV + baseS[it] + (ex >> 16), dump);
-    }
-  };
-  if (wide)
-    scatter_all(std::true_type{});
-  else
-    scatter_all(std::false_type{});
-  if constexpr (WAVES > 1) {
-    __syncthreads();
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  }
-  {
-    const uint32_t n_dw = (nV + nS) << (wide ? 1 : 0);
-    uint32_t *dst = a.vis + ((size_t)frame * tiles_per_frame + tile) * ((size_t)PIX_SLOT << (wide ? 1 : 0));
-    for (uint32_t i = threadIdx.x * 4u; i < n_dw; i += 64u * WAVES * 4u) // (a 16-byte unit may end past the list: stage and slot are PIX_SLOT long)
-      *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(stage + i);
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
-  if (lane == 0 && wave == 0)
-    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, nV | (nS << WORK_CNT_BITS) | (lp_mode ? WORK_LP : 0u), cnt, off);
+  if (tile_has_owner && lane == 0 && wave == 0)
+    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, lp_mode ? WORK_LP : 0u, cnt, off);
 }
 
 // ================================================================================================================
@@ -1766,9 +1713,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
 // ================================================================================================================
 template <bool STATS>
 __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_planes[2 * TILE * LDS_STRIDE + 128]; // z plane | owner plane (one block: the pixel lists' stage) | dummy slots
-  float *const zl = reinterpret_cast<float *>(s_planes);
-  uint32_t *const il = s_planes + TILE * LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) float zl[TILE * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t il[TILE * LDS_STRIDE];
   const int lane = threadIdx.x & 63;
   const uint32_t tiles_per_frame = a.n_local_bands * a.tiles_x;
   const uint32_t n_slow = *as_const(a.slow_count);
@@ -1954,35 +1900,14 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         }
       }
     }
-    if (tile_has_owner) { // the tile's two pixel lists (as k_raster): assembled in the z plane's LDS, whose values have left
-      uint4 id4[4];
-      uint32_t cnt2[4], incl2[4], baseV[4], baseS[4], nV = 0, nS = 0;
+    if (tile_has_owner) { // the owners of all of the tile's pixels, by index (32 bits each), and the tile's work entry
+      uint32_t *slot = a.vis + (size_t)entry * PIX_SLOT;
       for (int it = 0; it < 4; ++it) {
-        id4[it] = *reinterpret_cast<const uint4 *>(&il[(it * 8 + (lane >> 3)) * LDS_STRIDE + (lane & 7) * 4]);
-        cnt2[it] = strip_counts(id4[it], incl2[it]);
-        const uint32_t t2 = (uint32_t)rl_i((int)incl2[it], 63);
-        baseV[it] = nV, baseS[it] = nS, nV += t2 & 0xffffu, nS += t2 >> 16;
+        const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+        ids_store4(slot, (uint32_t)(ly * TILE + lx4), *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]), false);
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the z reads of the write-out stay in front of the stage's stores)
-      __builtin_amdgcn_wave_barrier();
-      const bool wide = a.wide_ids != 0u;
-      uint32_t *const stage = s_planes; // (wide lists: 2 x PIX_SLOT dwords = both planes; the owner plane has been read into id4)
-      static_assert(TILE * LDS_STRIDE == (int)PIX_SLOT, "the stage of a wide list spans both planes");
-      for (int it = 0; it < 4; ++it) { // (dummy slots of the unowned pixels: behind the lists)
-        const uint32_t p0 = (uint32_t)((it * 8 + (lane >> 3)) * TILE + (lane & 7) * 4), ex = incl2[it] - cnt2[it];
-        if (wide)
-          strip_scatter<true>(stage, id4[it], p0, baseV[it] + (ex & 0xffffu), nV + baseS[it] + (ex >> 16), PIX_SLOT + (uint32_t)lane);
-        else
-          strip_scatter<false>(stage, id4[it], p0, baseV[it] + (ex & 0xffffu), nV + baseS[it] + (ex >> 16), PIX_SLOT + (uint32_t)lane);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t n_dw = (nV + nS) << (wide ? 1 : 0);
-      uint32_t *dst = a.vis + (size_t)entry * ((size_t)PIX_SLOT << (wide ? 1 : 0));
-      for (uint32_t i = (uint32_t)lane * 4u; i < n_dw; i += 256u) *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(stage + i);
-      if (lane == 0) work_append(a, fd->flags, frame, entry, nV | (nS << WORK_CNT_BITS), 0u, 0u); // (owners by index)
+      if (lane == 0) work_append(a, fd->flags, frame, entry, 0u, 0u, 0u);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
   }
   if (STATS) {
@@ -2064,7 +1989,11 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
   static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
   static_assert(!(GENPOW && BUMPY), "frames with BUMP / DISPLACEMENT batches and a non-integer exponent take the generic build");
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_ent[PIX_SLOT];     // the tile's pixel lists (wide lists are read from global memory per chunk)
+  // the tile's owned pixels compacted by class: V entries [0, nV), S entries [nV, nV + nS), row-major each; an entry = pixel |
+  // owner's list position << 10 — or, for tiles whose ids are triangle indices, {pixel, index} pairs in s_tri's memory (no
+  // triangles are staged for those)
+  __shared__ __attribute__((aligned(16))) uint32_t s_ent[PIX_SLOT];
+  __shared__ uint32_t s_wcnt[4];                                        // per wave: V-class | S-class << 16 pixels among its 256
   // the triangles of the tile's list, staged once per tile (96 bytes each, by list position) + their batch ids, and the frame's
   // shader descriptors: a pixel takes its owner's data from here instead of gathering it from memory — 26 KB of LDS in all,
   // six workgroups per CU as before
@@ -2077,24 +2006,33 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long n_vis = 0, n_vis_tex = 0;
   const uint32_t tpf = a.n_local_bands * a.tiles_x;
-  const bool wide = a.wide_ids != 0u; // wave-uniform
 
   // ---- one owned tile: x = its work-list entry (work_append).  mode: 0 = FAST variants, 1 = generic (FastMath, then IEEE if
   //      needed), 2 = IEEE at once -------------------------------------------------------------------------------------------------
   auto shade_tile = [&](const u32x4 x, auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
-    const uint32_t nV = x.y & WORK_CNT_MASK, nS = (x.y >> WORK_CNT_BITS) & WORK_CNT_MASK;
-    // how the lists name a pixel's owner: by position in the tile's triangle list — the list's triangles are staged in LDS if they
-    // fit (by_lp && staged), else looked up per pixel (by_lp) — or by index in the frame
+    // (everything a thread derives from its index is derived HERE, per tile, from an opaque copy: hoisted out of the tile loop
+    // those values live across the chunk loops, get spilled, and every tile starts with scratch round trips in front of its loads)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    // how the tile's ids name a pixel's owner: by position in the tile's triangle list (16-bit ids) — the list's triangles are
+    // staged in LDS if they fit (by_lp && staged), else looked up per pixel (by_lp) — or by index in the frame (32-bit ids)
     const bool by_lp = (x.y & WORK_LP) != 0u, staged = by_lp && x.z <= STAGE_TRIS; // workgroup-uniform
     const SRZ_CAS uint32_t *tlist = as_const(a.pool) + x.w;
-    // ---- 1. the tile's pixel lists (written by the rasteriser: V pixels, then S pixels, row-major each) → LDS, one coalesced
-    //         load whose address needs nothing but the entry: it is in flight under the frame descriptor's scalar loads
-    //         (issued here, parked in LDS only in front of the barrier below)
-    const SRZ_CAS uint32_t *ent_g = as_const(a.vis) + (size_t)x.x * ((size_t)PIX_SLOT << (wide ? 1 : 0));
-    const bool ent_lo = !wide && (uint32_t)tid * 4u < nV + nS;
-    u32x4 ent0 = {0u, 0u, 0u, 0u};
-    if (ent_lo) ent0 = reinterpret_cast<const SRZ_CAS u32x4 *>(ent_g)[tid];
+    // ---- 1. this thread's 4 pixels: their owner ids (nothing but the entry is needed for the address: the load is in flight
+    //         under the frame descriptor's scalar loads), and the indices of the list entries whose pieces it will stage
+    const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
+    const int p0 = ly * TILE + lx4;
+    const uint4 id4 = ids_load4(a.vis + (size_t)x.x * PIX_SLOT, (uint32_t)p0, by_lp);
+    constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
+    const uint32_t n_pc = staged ? x.z * 6u : 0u;
+    uint32_t ti[PASSES];
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const uint32_t pc = (uint32_t)tid + 256u * k;
+      ti[k] = pc < n_pc ? tlist[pc / 6u] : 0u;
+    }
     const uint32_t f = x.x / tpf, e = x.x % tpf;
     const uint32_t tx = e % a.tiles_x, lb = e / a.tiles_x;
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
@@ -2114,30 +2052,6 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
     const size_t row0 = (size_t)lb * BAND;
     float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
 
-    // ---- 1b. the tile's triangles → LDS: 16-byte piece q of list entry l per thread (six threads per triangle, coalesced 96
-    //          bytes), the index loads of all of a thread's pieces in flight together, then the pieces themselves
-    if (staged) {
-      constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
-      const uint32_t n_pc = x.z * 6u;
-      uint32_t ti[PASSES];
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k) {
-        const uint32_t pc = (uint32_t)tid + 256u * k;
-        ti[k] = pc < n_pc ? tlist[pc / 6u] : 0u;
-      }
-      // (LDS-DMA: the 16-byte pieces go from memory straight to LDS — the wave's 64 pieces land one after the other at a
-      // wave-uniform base, which is s_tri's own order — and hold no registers while in flight; the barrier below drains them)
-#pragma unroll
-      for (int k = 0; k < PASSES; ++k) {
-        const uint32_t pc = (uint32_t)tid + 256u * k;
-        if (pc < n_pc) {
-          const uint32_t q = pc % 6u;
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(a.tris + tri_off + ti[k]) + q,
-                                           (__attribute__((address_space(3))) void *)(s_tri + (wave * 64 + 256 * k)), 16, 0, 0);
-          if (q == 0u) s_bat[pc / 6u] = tri_batch[ti[k]];
-        }
-      }
-    }
     if (sd_staged && (uint32_t)tid < fd->n_batches) {
       const SRZ_CAS ShadeDescG *g = sdesc + tid;
       ShadeDescG d;
@@ -2148,7 +2062,6 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
     // ---- 2. the colour staging planes start as what the pixels this call does not own must hold: 0 after the fused clear, else
     //         the colour already in the framebuffer (the z plane is not read: the shader's depth is recomputed from the owner
     //         triangle with k_raster's own operations, which is cheaper than 4 bytes per pixel of HBM read)
-    const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int y = ty0 + ly, x4 = tx0 + lx4;
     const bool in_tile = y <= ty1 && x4 <= tx1;
     const bool full = in_tile && ((W & 3) == 0) && x4 + 3 <= tx1;
@@ -2166,13 +2079,59 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
 #undef SRZ_LD
       }
     }
-    const int p0 = ly * TILE + lx4;
     *reinterpret_cast<float4 *>(&s_c[0][p0]) = C0;
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
     *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
+    // classify this thread's 4 pixels: per-thread counts, one packed wave scan (DPP), the waves' totals through LDS
+    const uint32_t idk[4] = {id4.x, id4.y, id4.z, id4.w};
+    uint32_t cnt2 = 0; // V count | S count << 16 of this thread
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt2 += idk[k] == NO_TRI ? 0u : ((idk[k] & S_CLASS_BIT) ? 0x10000u : 1u);
+    const uint32_t incl2 = wave_scan_add(cnt2);
+    if (lane == 63) s_wcnt[wave] = incl2;
     if (tid == 0) s_flag = 0;
-    if (ent_lo) *reinterpret_cast<u32x4 *>(&s_ent[tid * 4]) = ent0;
-    __syncthreads();
+    // ---- 1b. the tile's triangles → LDS by DMA: 16-byte piece q of list entry l per thread (six threads per triangle: coalesced
+    //          96 bytes).  The pieces go from memory straight to LDS — the wave's 64 land one after the other at a wave-uniform
+    //          base, which is s_tri's own order — and hold no registers while in flight, under the compaction below
+    if (staged) {
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const uint32_t pc = (uint32_t)tid + 256u * k;
+        if (pc < n_pc) {
+          const uint32_t q = pc % 6u;
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(a.tris + tri_off + (ti[k] & PACK_IDX_MASK)) + q,
+                                           (__attribute__((address_space(3))) void *)(s_tri + (wave * 64 + 256 * k)), 16, 0, 0);
+          if (q == 0u) s_bat[pc / 6u] = (uint16_t)(ti[k] >> PACK_IDX_BITS); // (by_lp = FD_PACKED: the list entry carries the batch)
+        }
+      }
+    }
+    // raw barrier: only the LDS stores above must be visible (lgkmcnt); the DMA pieces stay in flight across it
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+    uint32_t bV = 0, bS = 0, nV = 0, nS = 0; // this wave's first slot in each list, list lengths (all wave-uniform)
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const uint32_t t2 = s_wcnt[w2];
+      bV += w2 < wave ? (t2 & 0xffffu) : 0u, bS += w2 < wave ? (t2 >> 16) : 0u, nV += t2 & 0xffffu, nS += t2 >> 16;
+    }
+    nV = (uint32_t)__builtin_amdgcn_readfirstlane((int)nV), nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)nS);
+    uint32_t *const s_ent2 = reinterpret_cast<uint32_t *>(s_tri); // ({pixel, index} pairs: tiles without staged triangles)
+    {
+      uint32_t oV = bV + ((incl2 - cnt2) & 0xffffu), oS = nV + bS + ((incl2 - cnt2) >> 16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool own = idk[k] != NO_TRI, isS = own && (idk[k] & S_CLASS_BIT) != 0;
+        const uint32_t o = isS ? oS : oV, owner = idk[k] & ~S_CLASS_BIT;
+        if (own) {
+          if (by_lp)
+            s_ent[o] = (uint32_t)(p0 + k) | (owner << PIX_BITS);
+          else
+            s_ent2[2 * o] = (uint32_t)(p0 + k), s_ent2[2 * o + 1] = owner;
+        }
+        oV += (own && !isS) ? 1u : 0u, oS += isS ? 1u : 0u;
+      }
+    }
+    __syncthreads(); // (also drains the DMA: an LDS-DMA is a pending LDS write on the vector-memory counter)
 
     // ---- 3. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
@@ -2196,12 +2155,11 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
         if (i >= (isV ? nV : nS)) continue;
         const uint32_t slot = isV ? i : nV + i;
         uint32_t p, id;
-        if (wide) { // (>= 2^22 triangles in a frame: not a throughput case)
-          const u32x2 en = reinterpret_cast<const SRZ_CAS u32x2 *>(ent_g)[slot];
-          p = en.x, id = en.y;
-        } else {
+        if (by_lp) {
           const uint32_t en = s_ent[slot];
           p = en & PIX_MASK, id = en >> PIX_BITS;
+        } else {
+          p = s_ent2[2 * slot], id = s_ent2[2 * slot + 1];
         }
         float r0 = 1.f, r1 = 2.f, r2 = 3.f;
         ShadeDesc sd;
@@ -2211,7 +2169,7 @@ __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FA
           late = s_tri + id * 6u; // (read inside the shading variant: early_fetch / late_fetch)
           tf.batch = s_bat[id];
         } else {
-          if (by_lp) id = tlist[id]; // (a list too long for the stage: position → index, then the gather)
+          if (by_lp) id = tlist[id] & PACK_IDX_MASK; // (a list too long for the stage: position → index, then the gather)
           fetch_tri(tris, tri_batch, id, tf);
         }
         const int px = tx0 + (int)(p & 31), py = ty0 + (int)(p >> 5);

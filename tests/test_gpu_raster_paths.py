@@ -301,11 +301,12 @@ def test_tight_rectangles_in_the_throughput_build(ctx, orc):
         same(got[i], ref, f"batch frame {i}")
 
 
-def test_wide_pixel_list_entries(orc, monkeypatch):
-    """frames with 2^22 triangles or more store {pixel, owner} dword pairs in the tiles' pixel lists (RenderArgs::wide_ids);
-    SRZ_WIDE_IDS (read when the ctx is created) forces that form: same planes bit for bit, both rasterisers, batch and single frame"""
+def test_owner_ids_by_triangle_index(orc, monkeypatch):
+    """frames of 2^22 - 1 triangles or more, or of more than 1024 batches, are not FD_PACKED: their tile lists hold plain triangle
+    indices, the owner ids are 32-bit indices and k_shade gathers the triangles per pixel instead of staging them.  SRZ_NO_PACKED
+    (read when the ctx is created) forces that form: same planes bit for bit, both rasterisers, batch and single frame"""
     import srz
-    monkeypatch.setenv("SRZ_WIDE_IDS", "1")
+    monkeypatch.setenv("SRZ_NO_PACKED", "1")
     c = srz.Context(0)
     c.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
     try:
@@ -318,14 +319,35 @@ def test_wide_pixel_list_entries(orc, monkeypatch):
             out.fill_(-2.0)
             fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR | extra, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            same(out[0].cpu().numpy(), ref, f"wide entries, batch, flags {extra}")
-            same(out[19].cpu().numpy(), orc.draw(scenes.config2(8, size=512))[1], "wide entries, frame 19")
+            same(out[0].cpu().numpy(), ref, f"ids by index, batch, flags {extra}")
+            same(out[19].cpu().numpy(), orc.draw(scenes.config2(8, size=512))[1], "ids by index, frame 19")
         fs.close()
         fs1 = c.frameset([f])                                                    # one frame: four waves per tile
         o1 = torch.zeros(fs1.out_shape, dtype=torch.float32, device="cuda")
         fs1.render(o1.data_ptr(), fs1.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        same(o1[0].cpu().numpy(), ref, "wide entries, single frame")
+        same(o1[0].cpu().numpy(), ref, "ids by index, single frame")
         fs1.close()
     finally:
         c.close()
+
+
+def test_long_tile_lists_and_many_batches(ctx, orc):
+    """tiles whose triangle list is longer than k_shade's LDS stage (96 entries: position -> index -> gather) and longer than the
+    tie-break's position field (512: ids by index), and a frame of 70 batches (more than the 16 staged shader descriptors): 600
+    small triangles stacked on a few tiles, every batch with its own shader type (half of the triangles survive the backface test)"""
+    rng = np.random.default_rng(77)
+    w, h = 160, 96
+    for n, nb in ((400, 3), (1800, 70)):
+        t = np.zeros(n, abi.TRI_DTYPE)
+        c = rng.uniform([20, 20], [60, 60], (n, 2))
+        t["pos"][:, :, :2] = c[:, None, :] + rng.uniform(-14, 14, (n, 3, 2))
+        t["pos"][:, :, 2] = rng.uniform(2, 60, (n, 1)) + rng.uniform(-1, 1, (n, 3))
+        nn = rng.normal(size=(n, 3, 3))
+        t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+        t["uv"] = rng.uniform(0, 1, (n, 3, 2))
+        cuts = np.linspace(0, n, nb + 1).astype(int)
+        shaders = [abi.SHADER_NORMAL, abi.SHADER_PHONG, abi.SHADER_TEXTURE]
+        batches = [(shaders[b % 3], scenes.TEX_SPOT if b % 3 == 2 else -1, t[cuts[b]:cuts[b + 1]]) for b in range(nb)]
+        lights = [((100.0, 100.0, -50.0), (300.0, 300.0, 300.0)), ((40.0, 50.0, 80.0), (200.0, 200.0, 200.0))]
+        both_paths(ctx, orc, lambda extra: abi.Frame(w, h, (0.0, 0.0, 0.9), lights, batches, abi.FUSED_CLEAR | extra), what=f"long lists {n}/{nb}")
