@@ -38,7 +38,7 @@ extern "C" {
  *   3  `stream` arguments: NULL = the ctx's own stream, SRZ_STREAM_NULL = HIP's null stream (was: NULL = null stream);
  *      srz_comm_*, srz_frameset_allgather / _deinterleave / _exchange_bytes, srz_kernel_time_samples
  *   4  srz_frameset_allgather_inplace, srz_frameset_gathered_row_offset, srz_frameset_read_gathered_frame
- *   5  srz_set_option; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
+ *   5  srz_set_option, srz_verify_fastpow; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
  */
 #define SRZ_ABI_VERSION 5
 
@@ -305,6 +305,11 @@ int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4);
 /* Same for the division-by-reciprocal sequence of the scalar-tail shaders (texel / 255, intensity / distance):
  * out3 = { pairs tested, mismatches vs a / b on pseudo-random in-range pairs, mismatches of texel / 255 for texel 0..255 }. */
 int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3);
+/* Same for the optimistic x^p of the shading builds for non-integer exponents (exp2(p log2 x) in binary64 with a rounding-safety
+ * flag): every binary32 x in [2^-40, 1] at exponent p (a non-integer in (0, 4096]) against the correctly rounded path.
+ * out4 = { operands, results that differ although the flag was clear (must be 0), flagged operands with a normal result >= 2^-120
+ * (ambiguous roundings), flagged operands with a smaller result } — the tiles of flagged pixels are shaded by the generic build. */
+int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
 

@@ -171,8 +171,8 @@ void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &
 
 // Which frames the FAST builds of k_shade can shade: 1..4 lights (Shader::p is 150 as the reference ships it, src/Shader.cpp:10;
 // any light count and exponent are legal there, src/Shader.cpp:192-386) — every shader type qualifies.  An integer exponent
-// 0 <= p <= 256 takes the builds with the exact multiplication chains, any other exponent the builds whose power is pow_cr
-// (FD_GENPOW; not combined with BUMP / DISPLACEMENT batches: those frames take the generic build).  Sets FD_FAST_SHADE + the
+// 0 <= p <= 256 takes the builds with the exact multiplication chains, a non-integer exponent in (0, 4096] the builds whose power
+// is pow_fast (FD_GENPOW; not combined with BUMP / DISPLACEMENT batches), every other exponent the generic build.  Sets FD_FAST_SHADE + the
 // light count in the host copies of the descriptors.
 void classify_frames(srz_frameset *fs) {
   fs->fast_mask = 0, fs->any_generic = false;
@@ -183,7 +183,8 @@ void classify_frames(srz_frameset *fs) {
       const int sh = fs->h_batches[d.batch_off + b].shader;
       bumpy = bumpy || sh == SRZ_SHADER_BUMP || sh == SRZ_SHADER_DISPLACEMENT;
     }
-    const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && (intpow || !bumpy);
+    const bool fracpow = d.p > 0.0f && d.p <= 4096.0f && d.p != std::trunc(d.p); // (pow_fast's domain)
+    const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && (intpow || (fracpow && !bumpy));
     d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | FD_PACKED | (7u << FD_NL_SHIFT))) |
               (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (intpow ? 0u : FD_GENPOW)) : 0u) |
               ((d.n_tris < PACK_IDX_MASK && d.n_batches <= PACK_MAX_BATCHES && !fs->no_packed) ? FD_PACKED : 0u);
@@ -1186,6 +1187,19 @@ int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3) {
   HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 3; ++i) out3[i] = h[i];
+  return SRZ_OK;
+}
+
+int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4) {
+  if (!ctx || !out4) return SRZ_E_INVALID;
+  if (!(p > 0.0f && p <= 4096.0f) || p == std::trunc(p)) return fail(ctx, SRZ_E_INVALID, "srz_verify_fastpow: p must be a non-integer in (0, 4096]");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  launch_verify_fastpow(ctx->d_stats, p, ctx->stream);
+  unsigned long long h[4];
+  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 4; ++i) out4[i] = h[i];
   return SRZ_OK;
 }
 

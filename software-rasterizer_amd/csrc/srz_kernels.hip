@@ -226,17 +226,73 @@ __device__ __forceinline__ float pow_int_cr(float x, float p) {
 }
 // Compile-time knowledge a shading variant may have (k_shade picks the variant per 64-pixel chunk, wave-uniformly):
 //   SH   >= 0: every pixel of the chunk uses shader type SH; -1: per-pixel type (sd.shader)
-//   NL   >  0: the frame has exactly NL lights (1..4) (decided on the host): the light loop is unrolled, the light constants sit
-//              in SGPRs;  0: run-time count
-//   NL   < 0 : the same for -NL lights, but the exponent is NOT an integer 0..256 (Shader::p is a mutable static in the reference,
-//              src/Shader.cpp:10: any value is legal): the power is pow_cr, as in the generic build.  With NL > 0 the exponent is
-//              an integer 0 <= p <= 256: the fixed chain for p = 150 (the value the reference ships) or the scalar
-//              square-and-multiply loop
-template <int NL> __device__ __forceinline__ float pow_frame(float x, float p) {
-  if constexpr (NL > 0)
+//   NL   != 0: the frame has exactly |NL| lights (1..4) (decided on the host): the light loop is unrolled, the light constants sit
+//              in SGPRs;  0: run-time count.  The sign of NL selects the exponent form (pow_frame)
+// x^p for a NON-INTEGER exponent 0 < p <= 4096 (wave-uniform), OPTIMISTICALLY: exp2(p * log2(x)) in binary64 — log by the
+// atanh series of (m - 1) / (m + 1) on the mantissa in (sqrt(1/2), sqrt(2)], p * e kept exact, 2^r by its Taylor polynomial —
+// about 45 binary64 operations where ocml's correctly rounded pow takes ~210.  Its error is below (2.4 p + 4) ulps of the binary64
+// result (log2(m): 7 roundings of 2^-53 on |t| <= 0.5, times p ln 2; the two series' tails are below 2^-55; 2^r: 4 more), so the
+// binary32 rounding of the result is the rounding of the exact x^p — hence of any correctly rounded or 1-ulp binary64 pow, the
+// oracle's and ocml's alike — unless the result lies within 32 + 4 p binary64 ulps of a binary32 rounding boundary (for
+// p = 7.5: 2.3e-7 of the operands) or in the subnormal range: then `amb` is set, and the caller hands the pixel's tile to the
+// generic build (pow_cr) exactly like an operand outside FastMath's range.  x = ±0 gives +0 (p is positive and no odd integer),
+// a result below 2^-151 rounds to +0; other non-positive, non-finite or NaN operands set `amb`.
+// Checked on the device against pow_cr for every binary32 x in (0, 1] at several exponents (k_verify_fastpow, tests/test_gpu_fastmath.py).
+__device__ __forceinline__ float pow_fast(float x, float p, bool &amb) {
+  const double xd = (double)x;
+  const uint64_t xb = __builtin_bit_cast(uint64_t, xd);
+  int e = (int)((xb >> 52) & 0x7ffu) - 1023;
+  double m = __builtin_bit_cast(double, (xb & 0x000fffffffffffffull) | 0x3ff0000000000000ull); // [1, 2)
+  const bool hi = m > 1.4142135623730951;
+  m = hi ? m * 0.5 : m, e += hi ? 1 : 0;
+  const double f = m - 1.0, g = m + 1.0; // (exact: m has 24 significant bits)
+  // s = f / g: reciprocal by Newton, then one correction of the quotient (error < 1 ulp)
+  double rg = __builtin_amdgcn_rcp(g);
+  rg = __builtin_fma(__builtin_fma(-g, rg, 1.0), rg, rg);
+  rg = __builtin_fma(__builtin_fma(-g, rg, 1.0), rg, rg);
+  double sq = f * rg;
+  sq = __builtin_fma(__builtin_fma(-g, sq, f), rg, sq);
+  const double z = sq * sq; // <= 0.02944
+  // log(m) = 2 s (1 + z/3 + z^2/5 + ... + z^9/19): the tail is below 2^-53
+  double P = 1.0 / 19.0;
+  P = __builtin_fma(P, z, 1.0 / 17.0), P = __builtin_fma(P, z, 1.0 / 15.0), P = __builtin_fma(P, z, 1.0 / 13.0);
+  P = __builtin_fma(P, z, 1.0 / 11.0), P = __builtin_fma(P, z, 1.0 / 9.0), P = __builtin_fma(P, z, 1.0 / 7.0);
+  P = __builtin_fma(P, z, 1.0 / 5.0), P = __builtin_fma(P, z, 1.0 / 3.0), P = __builtin_fma(P, z, 1.0);
+  const double t = (2.0 * sq) * P * 1.4426950408889634; // log2(m), |t| <= 0.5
+  const double pd = (double)p, yh = pd * (double)e /* exact: 24 x 11 bits */, yl = pd * t;
+  const double n = __builtin_rint(yh + yl), r = (yh - n) + yl; // (yh - n is exact), |r| <= 0.5 + tiny
+  const double u = r * 0.6931471805599453;
+  double Q = 1.0 / 6227020800.0; // exp(u), |u| <= 0.3466: Taylor to u^13 / 13!
+  Q = __builtin_fma(Q, u, 1.0 / 479001600.0), Q = __builtin_fma(Q, u, 1.0 / 39916800.0), Q = __builtin_fma(Q, u, 1.0 / 3628800.0);
+  Q = __builtin_fma(Q, u, 1.0 / 362880.0), Q = __builtin_fma(Q, u, 1.0 / 40320.0), Q = __builtin_fma(Q, u, 1.0 / 5040.0);
+  Q = __builtin_fma(Q, u, 1.0 / 720.0), Q = __builtin_fma(Q, u, 1.0 / 120.0), Q = __builtin_fma(Q, u, 1.0 / 24.0);
+  Q = __builtin_fma(Q, u, 1.0 / 6.0), Q = __builtin_fma(Q, u, 0.5), Q = __builtin_fma(Q, u, 1.0), Q = __builtin_fma(Q, u, 1.0);
+  const double nc = __builtin_fmax(__builtin_fmin(n, 1000.0), -1000.0); // (keeps ldexp's exponent an int)
+  const double res = __builtin_ldexp(Q, (int)nc);
+  const uint32_t lo = (uint32_t)__builtin_bit_cast(uint64_t, res) & 0x1fffffffu; // the 29 bits binary32 drops
+  const uint32_t dist = lo > 0x10000000u ? lo - 0x10000000u : 0x10000000u - lo; // to the rounding boundary, in binary64 ulps
+  const bool zero_in = (__builtin_bit_cast(uint32_t, x) << 1) == 0u;            // x = ±0
+  const bool tiny = res < 0x1p-151, normal = res >= 0x1p-120 && res < 0x1p+120;
+  const bool okx = x > 0.0f && x < __builtin_inff();
+  const uint32_t safe = 32u + (uint32_t)(4.0f * p); // (scalar: p is wave-uniform)
+  amb |= !(zero_in | (okx & (tiny | (normal & (dist > safe)))));
+  return (zero_in | tiny) ? 0.0f : (float)res;
+}
+
+// The exponent forms of the shading builds (NL = the build's compile-time light count, see k_shade):
+//   NL > 0  an integer exponent 0 <= p <= 256 (decided on the host): the fixed chain for p = 150 (the value the reference ships,
+//           src/Shader.cpp:10) or the scalar square-and-multiply loop
+//   NL < 0  a non-integer exponent in (0, 4096] (Shader::p is a mutable static in the reference: any value is legal): pow_fast,
+//           whose ambiguous cases the FastMath pass's `bad` flag takes to the generic build
+//   NL = 0  the generic build, every other exponent: pow_cr
+template <int NL, class M> __device__ __forceinline__ float pow_frame(M &m, float x, float p) {
+  if constexpr (NL > 0) {
     return p == 150.0f ? pow150_cr(x) : pow_int_cr(x, p); // (wave-uniform branch: p is a per-frame scalar)
-  else
+  } else if constexpr (NL < 0 && std::is_same<M, FastMath>::value) {
+    return pow_fast(x, p, m.bad); // (the host sends only frames with a non-integer exponent in (0, 4096] to these builds)
+  } else {
     return pow_cr(x, p);
+  }
 }
 template <int NL> constexpr int light_count() { return NL < 0 ? -NL : NL; } // lights known at compile time (0: run-time count)
 
@@ -840,7 +896,7 @@ __device__ __forceinline__ void v_blinn_phong(M &m, float nx, float ny, float nz
   float nlx = lx, nly = ly, nlz = lz;
   v_normalized(m, nlx, nly, nlz);
   float cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
-  float cosT = pow_frame<NL>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+  float cosT = pow_frame<NL>(m, sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
   o0 = kdr * fmaf_(K.ka[0], I0, fmaf_(d0 * kdr, cosA, (d0 * K.ks[0]) * cosT));
   o1 = kdg * fmaf_(K.ka[1], I1, fmaf_(d1 * kdg, cosA, (d1 * K.ks[1]) * cosT));
   o2 = kdb * fmaf_(K.ka[2], I2, fmaf_(d2 * kdb, cosA, (d2 * K.ks[2]) * cosT));
@@ -863,7 +919,7 @@ __device__ __forceinline__ void v_blinn_phong_terms(M &m, float nx, float ny, fl
   float nlx = lx, nly = ly, nlz = lz;
   v_normalized(m, nlx, nly, nlz);
   t.cosA = sse_max(0.0f, fmaf_(nlx, nx, fmaf_(nly, ny, nlz * nz)));
-  t.cosT = pow_frame<NL>(sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
+  t.cosT = pow_frame<NL>(m, sse_max(0.0f, fmaf_(hx, nx, fmaf_(hy, ny, hz * nz))), K.p);
 }
 __device__ __forceinline__ void v_blinn_phong_combine(const FrameK &K, const SRZ_CAS srz_light *L, const LightTerms &t, float kdr,
                                                       float kdg, float kdb, float &o0, float &o1, float &o2) {
@@ -963,7 +1019,7 @@ __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, f
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
   normalize3(m, hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
-  float pw = pow_frame<NL>(cosAlpha, K.p);
+  float pw = pow_frame<NL>(m, cosAlpha, K.p);
   o0 = ((K.ka[0] * I0 + (cosTheta * kd0) * d0) + (pw * K.ks[0]) * d0) * kd0;
   o1 = ((K.ka[1] * I1 + (cosTheta * kd1) * d1) + (pw * K.ks[1]) * d1) * kd1;
   o2 = ((K.ka[2] * I2 + (cosTheta * kd2) * d2) + (pw * K.ks[2]) * d2) * kd2;
@@ -985,7 +1041,7 @@ __device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float
   float hx = ldx + vx, hy = ldy + vy, hz = ldz + vz;
   normalize3(m, hx, hy, hz);
   float cosAlpha = std_max(0.0f, dot3(nx, ny, nz, hx, hy, hz));
-  t.cosT = pow_frame<NL>(cosAlpha, K.p);
+  t.cosT = pow_frame<NL>(m, cosAlpha, K.p);
 }
 __device__ __forceinline__ void s_blinn_phong_combine(const FrameK &K, const SRZ_CAS srz_light *L, const LightTerms &t, float kd0,
                                                       float kd1, float kd2, float &o0, float &o1, float &o2) {
@@ -1971,6 +2027,9 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 #define SRZ_STAGE_TRIS 96 // triangles of a tile's list k_shade stages in LDS (12 KB colours + 4 KB lists + 9 KB triangles: 6 workgroups per CU)
 #endif
 constexpr uint32_t STAGE_TRIS = SRZ_STAGE_TRIS, STAGE_SD = 16;
+#ifndef SRZ_GENPOW_MINW
+#define SRZ_GENPOW_MINW 5 // (the builds with pow_fast: 81 VGPRs for two lights; held to 80 they spill 20 bytes into the chunk loops: -3 %)
+#endif
 #ifndef SRZ_SHADE_MINW
 #define SRZ_SHADE_MINW 4
 #endif
@@ -1984,7 +2043,9 @@ constexpr uint32_t STAGE_TRIS = SRZ_STAGE_TRIS, STAGE_SD = 16;
 //   FASTNL < 0: the FAST build for -FASTNL lights and ANY exponent (pow_cr: ocml's binary64 pow for a non-integer one) — frames that
 //            differ from the common case only in Shader::p keep the per-chunk variants, the unrolled lights and the hoisted texel
 template <bool STATS, int FASTNL, bool BUMPY = false>
-__global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FAST_MINW : (FASTNL == 3 && !BUMPY) ? 5 : SRZ_SHADE_MINW) void k_shade(RenderArgs a) {
+__global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FAST_MINW : (FASTNL < 0 && FASTNL >= -2) ? SRZ_GENPOW_MINW
+                                  : ((FASTNL == 3 || FASTNL == -3) && !BUMPY) ? 5 : SRZ_SHADE_MINW)
+void k_shade(RenderArgs a) {
   constexpr bool FAST = FASTNL != 0, GENPOW = FASTNL < 0;
   static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
   static_assert(!(GENPOW && BUMPY), "frames with BUMP / DISPLACEMENT batches and a non-integer exponent take the generic build");
@@ -2460,6 +2521,35 @@ __global__ void k_verify_fastdiv(unsigned long long *out, uint32_t per_thread) {
 }
 void launch_verify_fastdiv(unsigned long long *d_out, hipStream_t s) {
   hipLaunchKernelGGL(k_verify_fastdiv, dim3(8192), dim3(256), 0, s, d_out, 2048u);
+}
+
+// Exhaustive check of pow_fast against pow_cr: every binary32 x in [2^-40, 1] (+ the operands above 1 the clamped cosines can
+// reach by rounding) at exponent p.  out[0] = operands, out[1] = results that differ although pow_fast did NOT flag them (must
+// be 0), out[2] = flagged operands whose result is a normal binary32 >= 2^-120 (ambiguous roundings: must stay rare), out[3] =
+// flagged operands with smaller results (the band 2^-151 .. 2^-120 is flagged wholesale; cosines that small are rare).
+__global__ void k_verify_fastpow(unsigned long long *out, float p) {
+  unsigned long long bad = 0, flagged = 0, flagged_small = 0, n = 0;
+  const uint32_t lo = 0x2b800000u /* 2^-40 */, hi = 0x3f800010u /* 1 + 16 ulp */;
+  for (uint64_t i = lo + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= hi; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __builtin_bit_cast(float, (uint32_t)i);
+    bool amb = false;
+    const float a = pow_fast(x, p, amb), b = pow_cr(x, p);
+    ++n, bad += (!amb && f2u_(a) != f2u_(b)) ? 1 : 0;
+    if (amb) (b >= 0x1p-120f ? flagged : flagged_small) += 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) { // the special operands: ±0 give +0 unflagged; negative, inf and NaN must be flagged
+    const float sp[4] = {0.0f, -0.0f, -1.0f, __builtin_inff()};
+    bool amb = false;
+    const float a = pow_fast(sp[threadIdx.x], p, amb);
+    bad += threadIdx.x < 2 ? (amb || f2u_(a) != 0u) : !amb;
+  }
+  atomicAdd(&out[0], n);
+  if (bad) atomicAdd(&out[1], bad);
+  if (flagged) atomicAdd(&out[2], flagged);
+  if (flagged_small) atomicAdd(&out[3], flagged_small);
+}
+void launch_verify_fastpow(unsigned long long *d_out3, float p, hipStream_t s) {
+  hipLaunchKernelGGL(k_verify_fastpow, dim3(8192), dim3(256), 0, s, d_out3, p);
 }
 
 // BGR u8 (row_stride bytes per row) → one dword per texel

@@ -24,3 +24,19 @@ def test_division_by_reciprocal_matches_ieee_division():
     ctx.close()
     assert n == 8192 * 256 * 2048
     assert (bad_pairs, bad_texel) == (0, 0)
+
+
+@pytest.mark.parametrize("p", [7.5, 2.5, 0.3, 33.3, 149.99, 1000.7, 4095.5])
+def test_optimistic_pow_equals_the_correctly_rounded_one_wherever_it_does_not_flag(p):
+    """pow_fast (the FAST k_shade builds for non-integer exponents: exp2(p log2 x) in binary64, ~45 operations) against pow_cr
+    (binary64 pow rounded once) for EVERY binary32 x in [2^-40, 1 + 16 ulp]: wherever its rounding-safety flag is clear the
+    results must be bit-identical; flagged operands (their tile goes to the generic build) must stay rare"""
+    import srz
+    ctx = srz.Context(0)
+    n, bad, flagged, flagged_small = ctx.verify_fastpow(p)
+    ctx.close()
+    assert n == 0x3f800010 - 0x2b800000 + 1
+    assert bad == 0, (p, bad)
+    # ambiguous roundings: within 32 + 4 p binary64 ulps of a binary32 rounding boundary = 2 (32 + 4 p) / 2^29 of the normal results
+    # (the band of results 2^-151 .. 2^-120 is flagged wholesale and counted apart)
+    assert flagged < 100 + n * 4 * (32 + 4 * p) / 2 ** 29, (p, flagged, flagged_small, n)
