@@ -2077,15 +2077,22 @@ void k_shade(RenderArgs a) {
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
+    // (likewise the kernel's arguments: read from the kernarg segment per tile — scalar loads that hit the constant cache —
+    // through an opaque pointer.  Loaded once at kernel entry they are ~50 scalar registers alive across everything: the compiler
+    // parks them in VGPR lanes (v_writelane) and fetches them back with a VALU instruction each (v_readlane), 8 % of the
+    // kernel's vector instructions)
+    const SRZ_CAS RenderArgs *ap = (const SRZ_CAS RenderArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const uint32_t tpf = ap->n_local_bands * ap->tiles_x;
     // how the tile's ids name a pixel's owner: by position in the tile's triangle list (16-bit ids) — the list's triangles are
     // staged in LDS if they fit (by_lp && staged), else looked up per pixel (by_lp) — or by index in the frame (32-bit ids)
     const bool by_lp = (x.y & WORK_LP) != 0u, staged = by_lp && x.z <= STAGE_TRIS; // workgroup-uniform
-    const SRZ_CAS uint32_t *tlist = as_const(a.pool) + x.w;
+    const SRZ_CAS uint32_t *tlist = as_const(ap->pool) + x.w;
     // ---- 1. this thread's 4 pixels: their owner ids (nothing but the entry is needed for the address: the load is in flight
     //         under the frame descriptor's scalar loads), and the indices of the list entries whose pieces it will stage
     const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int p0 = ly * TILE + lx4;
-    const uint4 id4 = ids_load4(a.vis + (size_t)x.x * PIX_SLOT, (uint32_t)p0, by_lp);
+    const uint4 id4 = ids_load4(ap->vis + (size_t)x.x * PIX_SLOT, (uint32_t)p0, by_lp);
     constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
     const uint32_t n_pc = staged ? x.z * 6u : 0u;
     uint32_t ti[PASSES];
@@ -2095,23 +2102,23 @@ void k_shade(RenderArgs a) {
       ti[k] = pc < n_pc ? tlist[pc / 6u] : 0u;
     }
     const uint32_t f = x.x / tpf, e = x.x % tpf;
-    const uint32_t tx = e % a.tiles_x, lb = e / a.tiles_x;
-    const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
+    const uint32_t tx = e % ap->tiles_x, lb = e / ap->tiles_x;
+    const SRZ_CAS FrameDesc *fd = as_const(ap->frames) + f;
     const int W = fd->width, H = fd->height;
     const uint32_t tri_off = fd->tri_off, batch_off = fd->batch_off;
-    const uint32_t flags = fd->flags | a.flags_or;
+    const uint32_t flags = fd->flags | ap->flags_or;
     const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
-    const SRZ_CAS srz_tri *tris = as_const(a.tris) + tri_off;
-    const SRZ_CAS uint16_t *tri_batch = as_const(a.tri_batch) + tri_off;
-    const SRZ_CAS ShadeDescG *sdesc = as_const(a.sdesc) + batch_off;
+    const SRZ_CAS srz_tri *tris = as_const(ap->tris) + tri_off;
+    const SRZ_CAS uint16_t *tri_batch = as_const(ap->tri_batch) + tri_off;
+    const SRZ_CAS ShadeDescG *sdesc = as_const(ap->sdesc) + batch_off;
     const bool sd_staged = fd->n_batches <= STAGE_SD; // workgroup-uniform
 
-    const int band = (int)lb * a.shard_world + a.shard_rank;
+    const int band = (int)lb * ap->shard_world + ap->shard_rank;
     const int tx0 = (int)tx * TILE, ty0 = band * BAND;
     const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
-    const size_t plane = (size_t)a.local_rows * (size_t)W;
+    const size_t plane = (size_t)ap->local_rows * (size_t)W;
     const size_t row0 = (size_t)lb * BAND;
-    float *out0 = a.out + (size_t)f * a.frame_stride + row0 * (size_t)W;
+    float *out0 = ap->out + (size_t)f * ap->frame_stride + row0 * (size_t)W;
 
     if (sd_staged && (uint32_t)tid < fd->n_batches) {
       const SRZ_CAS ShadeDescG *g = sdesc + tid;
@@ -2160,7 +2167,7 @@ void k_shade(RenderArgs a) {
         const uint32_t pc = (uint32_t)tid + 256u * k;
         if (pc < n_pc) {
           const uint32_t q = pc % 6u;
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(a.tris + tri_off + (ti[k] & PACK_IDX_MASK)) + q,
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(ap->tris + tri_off + (ti[k] & PACK_IDX_MASK)) + q,
                                            (__attribute__((address_space(3))) void *)(s_tri + (wave * 64 + 256 * k)), 16, 0, 0);
           if (q == 0u) s_bat[pc / 6u] = (uint16_t)(ti[k] >> PACK_IDX_BITS); // (by_lp = FD_PACKED: the list entry carries the batch)
         }
@@ -2209,10 +2216,12 @@ void k_shade(RenderArgs a) {
       K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
       K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
       K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
-      K.lights = as_const(a.lights) + fd->light_off;
-      for (uint32_t c = (uint32_t)wave; c < cV + cS; c += 4) { // chunk c of the tile: V chunks first, then S chunks
-        if ((c < cV) != isV) continue;
-        const uint32_t i = (isV ? c : c - cV) * 64 + lane;
+      K.lights = as_const(ap->lights) + fd->light_off;
+      // chunk c of the tile, dealt round-robin to the waves: the S chunks first (the dearer ones: ~450 instructions against ~310), so that
+      // the waves' loads differ by at most one V chunk at the barrier behind the passes
+      for (uint32_t c = (uint32_t)wave; c < cV + cS; c += 4) {
+        if ((c >= cS) != isV) continue;
+        const uint32_t i = (isV ? c - cS : c) * 64 + lane;
         if (i >= (isV ? nV : nS)) continue;
         const uint32_t slot = isV ? i : nV + i;
         uint32_t p, id;
@@ -2310,7 +2319,7 @@ void k_shade(RenderArgs a) {
     };
     bool skip_write = false;
     if constexpr (MODE == 2) {
-      if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
+      if (STATS && tid == 0) atomicAdd(&ap->stats[ST_DBG_IEEE_TILES], 1ull);
       dense_passes(IeeeMath{}, true);
       __syncthreads();
     } else {
@@ -2321,10 +2330,10 @@ void k_shade(RenderArgs a) {
       __syncthreads();
       if (s_flag) { // workgroup-uniform
         if constexpr (MODE == 0) { // hand the tile to the generic build
-          if (tid == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = make_uint4(x.x, x.y, x.z, x.w);
+          if (tid == 0) ap->redo_list[atomicAdd(ap->redo_count, 1u)] = make_uint4(x.x, x.y, x.z, x.w);
           skip_write = true;
         } else {
-          if (STATS && tid == 0) atomicAdd(&a.stats[ST_DBG_IEEE_TILES], 1ull);
+          if (STATS && tid == 0) atomicAdd(&ap->stats[ST_DBG_IEEE_TILES], 1ull);
           dense_passes(IeeeMath{}, false);
           __syncthreads();
         }
