@@ -131,7 +131,14 @@ struct IeeeMath {
   __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
 };
 struct FastMath {
-  bool bad = false;
+  bool bad = false; // (the rare checks: division operands, pow_fast's rounding flag)
+  // The operands of the reciprocals / square roots are tracked as the running unsigned minimum and maximum of their bit patterns
+  // (two instructions per operand instead of shift + subtract + compare + or; magnitudes for the signed ones) and tested ONCE per
+  // pixel: all inside [2^-100, 2^101) <=> lo >= 0x0d800000 and hi <= 0x71ffffff — the criterion of fast_range / fast_pos (a
+  // negative, NaN, infinite, zero or denormal operand of a positive-only operation breaks one of the two bounds)
+  uint32_t lo = 0x0d800000u, hi = 0x0d800000u;
+  __device__ __forceinline__ void track(uint32_t bits) { lo = lo < bits ? lo : bits, hi = hi > bits ? hi : bits; }
+  __device__ __forceinline__ bool is_bad() const { return bad | (lo < 0x0d800000u) | (hi > 0x71ffffffu); }
   // texel / 255.0f for texel = 0..255: numerator and divisor are always inside div_by_rcp's range
   __device__ __forceinline__ float div255(float a) { return div_by_rcp(a, 255.0f, __builtin_bit_cast(float, 0x3b808081u)); }
   // three numerators (wave-uniform light intensities) over one positive per-pixel divisor: one reciprocal
@@ -141,15 +148,15 @@ struct FastMath {
     q0 = div_by_rcp(a0, b, y), q1 = div_by_rcp(a1, b, y), q2 = div_by_rcp(a2, b, y);
   }
   __device__ __forceinline__ float rcp(float x) {
-    bad |= !fast_range(x);
+    track(f2u_(x) & 0x7fffffffu);
     return rcp_core(x);
   }
   __device__ __forceinline__ float sqrt(float x) {
-    bad |= !fast_pos(x);
+    track(f2u_(x));
     return sqrt_core(x);
   }
   __device__ __forceinline__ float rsqrt2(float d) { // sqrt(d) lies in [2^-50, 2^50]: inside rcp_core's range
-    bad |= !fast_pos(d);
+    track(f2u_(d));
     return rcp_core(sqrt_core(d));
   }
 };
@@ -177,7 +184,7 @@ template <class M> __device__ __forceinline__ void v_normalized(M &m, float &x, 
 // FastMath: a squared length inside the fast range has a positive, in-range square root — one check covers both steps
 __device__ __forceinline__ void v_normalized(FastMath &m, float &x, float &y, float &z) {
   const float d = fmaf_(x, x, fmaf_(y, y, z * z));
-  m.bad |= !fast_pos(d);
+  m.track(f2u_(d));
   const float inv = rcp_core(sqrt_core(d));
   x = x * inv, y = y * inv, z = z * inv;
 }
@@ -1293,11 +1300,11 @@ __global__ void probe_v(RenderArgs a, float *o) {
 #ifdef SRZ_PROBE_S
   FastMath fm;
   shade_pixel_s<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, nullptr, threadIdx.x, blockIdx.x, r0, r1, r2);
-  if (fm.bad) r0 = -1.f;
+  if (fm.is_bad()) r0 = -1.f;
 #else
   FastMath fm;
   shade_pixel_v<FastMath, SRZ_PROBE_SH, (SRZ_PROBE_SH >= 0 ? 2 : 0)>(fm, K, sd, tf, nullptr, threadIdx.x, blockIdx.x, r0, r1, r2);
-  if (fm.bad) r0 = -1.f;
+  if (fm.is_bad()) r0 = -1.f;
 #endif
   o[threadIdx.x] = r0 + r1 + r2;
 }
@@ -2299,7 +2306,7 @@ void k_shade(RenderArgs a) {
           else
             shade_pixel_s<M>(m, K, sd, tf, late, px, py, r0, r1, r2);
         }
-        if constexpr (std::is_same<M, FastMath>::value) bad |= m.bad;
+        if constexpr (std::is_same<M, FastMath>::value) bad |= m.is_bad();
         s_c[0][p] = r0, s_c[1][p] = r1, s_c[2][p] = r2;
         if (STATS && count)
           n_vis++, n_vis_tex += (sd.shader == SRZ_SHADER_TEXTURE || sd.shader == SRZ_SHADER_DISPLACEMENT || sd.shader == SRZ_SHADER_BUMP);
