@@ -2099,14 +2099,28 @@ void k_shade(RenderArgs a) {
     //         under the frame descriptor's scalar loads), and the indices of the list entries whose pieces it will stage
     const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int p0 = ly * TILE + lx4;
-    const uint4 id4 = ids_load4(ap->vis + (size_t)x.x * PIX_SLOT, (uint32_t)p0, by_lp);
+    // (raw: the 16-bit codes are classified as they are — position | 0x8000 for the S class, 0xffff = nobody —, never widened)
+    uint4 id4 = make_uint4(0u, 0u, 0u, 0u);
+    {
+      const uint32_t *slot = ap->vis + (size_t)x.x * PIX_SLOT;
+      if (by_lp) {
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint16_t *>(slot) + p0);
+        id4 = make_uint4(w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16);
+      } else {
+        id4 = *reinterpret_cast<const uint4 *>(slot + p0);
+      }
+    }
+    const uint32_t none = by_lp ? 0xffffu : NO_TRI, sbit = by_lp ? 0x8000u : S_CLASS_BIT; // (scalar)
     constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
     const uint32_t n_pc = staged ? x.z * 6u : 0u;
     uint32_t ti[PASSES];
 #pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-      const uint32_t pc = (uint32_t)tid + 256u * k;
-      ti[k] = pc < n_pc ? tlist[pc / 6u] : 0u;
+    for (int k = 0; k < PASSES; ++k) { // (passes the list does not reach are skipped by a SCALAR branch: most lists fit the first)
+      ti[k] = 0u;
+      if (n_pc > 256u * k) {
+        const uint32_t pc = (uint32_t)tid + 256u * k;
+        if (pc < n_pc) ti[k] = tlist[pc / 6u];
+      }
     }
     const uint32_t f = x.x / tpf, e = x.x % tpf;
     const uint32_t tx = e % ap->tiles_x, lb = e / ap->tiles_x;
@@ -2161,7 +2175,7 @@ void k_shade(RenderArgs a) {
     const uint32_t idk[4] = {id4.x, id4.y, id4.z, id4.w};
     uint32_t cnt2 = 0; // V count | S count << 16 of this thread
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cnt2 += idk[k] == NO_TRI ? 0u : ((idk[k] & S_CLASS_BIT) ? 0x10000u : 1u);
+    for (int k = 0; k < 4; ++k) cnt2 += idk[k] == none ? 0u : ((idk[k] & sbit) ? 0x10000u : 1u);
     const uint32_t incl2 = wave_scan_add(cnt2);
     if (lane == 63) s_wcnt[wave] = incl2;
     if (tid == 0) s_flag = 0;
@@ -2171,6 +2185,7 @@ void k_shade(RenderArgs a) {
     if (staged) {
 #pragma unroll
       for (int k = 0; k < PASSES; ++k) {
+        if (n_pc <= 256u * k) break; // scalar
         const uint32_t pc = (uint32_t)tid + 256u * k;
         if (pc < n_pc) {
           const uint32_t q = pc % 6u;
@@ -2195,8 +2210,8 @@ void k_shade(RenderArgs a) {
       uint32_t oV = bV + ((incl2 - cnt2) & 0xffffu), oS = nV + bS + ((incl2 - cnt2) >> 16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool own = idk[k] != NO_TRI, isS = own && (idk[k] & S_CLASS_BIT) != 0;
-        const uint32_t o = isS ? oS : oV, owner = idk[k] & ~S_CLASS_BIT;
+        const bool own = idk[k] != none, isS = own && (idk[k] & sbit) != 0;
+        const uint32_t o = isS ? oS : oV, owner = idk[k] & ~sbit;
         if (own) {
           if (by_lp)
             s_ent[o] = (uint32_t)(p0 + k) | (owner << PIX_BITS);
