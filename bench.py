@@ -56,16 +56,16 @@ PRIME_TO = 20      # untimed renders in front of every timed region, the --warmu
 
 
 def kernel_source_hash():
-    """sha256 over the device sources the PMC passes profiled (csrc/*.hip + csrc/srz_device.h + include/srz.h), first 16 hex
-    digits: profiles/summarize.py stores it in profiles/pmc_counters.json, and a bench line of OTHER sources reports
-    traffic: null + traffic_stale instead of another code version's counters"""
-    import glob
+    """sha256 of the built library that RUNS (software-rasterizer_amd/libsrz.so: kernels + C ABI), first 16 hex digits:
+    profiles/summarize.py stores it in profiles/pmc_counters.json next to the counters it collected with that library, and a
+    bench line of ANOTHER build reports traffic: null + traffic_stale instead of another code version's counters.  (The binary,
+    not the source text: a comment edit does not invalidate a profile, a flag or toolchain change does.)"""
     import hashlib
-    h = hashlib.sha256()
-    base = os.path.join(REPO, "software-rasterizer_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + [os.path.join(base, "srz_device.h"), os.path.join(REPO, "include", "srz.h")]):
-        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
-    return h.hexdigest()[:16]
+    lib = os.environ.get("SRZ_LIB_PATH", os.path.join(REPO, "software-rasterizer_amd", "libsrz.so"))
+    try:
+        return hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return "no-library"
 
 
 def launch_ranks(n_ranks, argv):

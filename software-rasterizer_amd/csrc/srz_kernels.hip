@@ -17,13 +17,16 @@
 //                                          LDS, every fragment is a ds_min_u64; the tile's (triangle, pixel) candidates are
 //                                          flattened into items (8 pixels of a bbox row / one scalar-tail pixel) and dealt
 //                                          densely to the 64 lanes.  Touched tiles nobody owns leave as the fused clear;
-//                                          owned tiles write z + owner ids and append themselves to their frame's work list.
+//                                          owned tiles write z + owner ids — 16 bits per pixel: the owner's POSITION in the tile's
+//                                          triangle list, which rides in the key's tie-break below the triangle index — and append
+//                                          themselves (with their list's length and offset) to their frame's work list.
 //   k_raster_slow  one wave per listed tile the reference's ORDERED algorithm for what the keys cannot express (NaN / ±0
 //                                          depths), for bands that did not fit the pool, and for counting runs.
 //   k_shade   one WORKGROUP per owned tile VISIBILITY-FIRST SHADING: each pixel's final owner is shaded exactly once (the
 //                                          reference's shaders are pure functions of (triangle,pixel) and its write is an
-//                                          overwrite), pixels compacted by semantics class into dense 64-lane chunks,
-//                                          16-byte stores of the 3 colour planes.
+//                                          overwrite), pixels compacted by semantics class into dense 64-lane chunks; the tile's
+//                                          listed triangles are staged in LDS once per tile (LDS-DMA) and read from there by list
+//                                          position; 16-byte stores of the 3 colour planes.
 //   k_resolve8                             (optional) display(): planes → BGR8.
 //
 // Numerics: every float op is the oracle's op in the oracle's order (oracle/srz_oracle.c): contraction is OFF,

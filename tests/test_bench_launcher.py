@@ -40,7 +40,7 @@ def test_launcher_runs_before_torch_is_imported():
     assert "\nimport torch" not in head and "\nfrom torch" not in head
 
 
-def test_pmc_counters_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+def test_pmc_counters_are_tied_to_the_library_build(tmp_path, monkeypatch):
     sys.path.insert(0, REPO)
     import bench
     h = bench.kernel_source_hash()
