@@ -2224,7 +2224,10 @@ void k_shade(RenderArgs a) {
         oV += (own && !isS) ? 1u : 0u, oS += isS ? 1u : 0u;
       }
     }
-    __syncthreads(); // (also drains the DMA: an LDS-DMA is a pending LDS write on the vector-memory counter)
+    // (the DMA pieces must have landed: an LDS-DMA is a pending LDS write on the vector-memory counter — the barrier's fence waits
+    // for it by itself with this compiler; the explicit wait states the requirement)
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0), expcnt / lgkmcnt untouched
+    __syncthreads();
 
     // ---- 3. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
