@@ -1152,17 +1152,18 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
 // A tile that has an owner goes to one of 104 work lists for k_shade: [build that shades the frame: FAST for 1 / 2 / 3 / 4 lights,
 // the same for frames with BUMP / DISPLACEMENT batches, the same for frames with a non-integer exponent, generic][frame % 8]
 // (frame % 8 = the XCD that rasterised it), in arrival order — k_raster's workgroups run in frame order, so every list comes
-// out (roughly) frame by frame.  An entry = {frame * tiles_per_frame + tile, flags (WORK_LP), entries of the tile's triangle
-// list, its first index in pool[]}: everything k_shade needs to start the tile's loads travels with it.
-constexpr uint32_t WORK_LP = 1u; // the tile's owner ids are POSITIONS in the tile's triangle list, 16 bits each (see LP_BITS)
-__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry, uint32_t wflags,
-                                            uint32_t list_cnt, uint32_t list_off) {
+// out (roughly) frame by frame.  An entry = {frame, local band | tile x << 10 | flags (WORK_LP), entries of the tile's triangle
+// list, its first index in pool[]}: everything k_shade needs to start the tile's loads travels with it, and nothing has to be
+// divided out of a flat tile number (two scalar software divisions per tile otherwise).
+constexpr uint32_t WORK_LP = 1u << 20; // the tile's owner ids are POSITIONS in the tile's triangle list, 16 bits each (see LP_BITS)
+__device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry /* frame * tiles + tile */,
+                                            uint32_t lb, uint32_t tx, uint32_t wflags, uint32_t list_cnt, uint32_t list_off) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
   const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
                             ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u) + ((frame_flags & FD_GENPOW) ? 8u : 0u)
                             : SHADE_KIND_GENERIC;
   const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
-  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(entry, wflags, list_cnt, list_off);
+  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(frame, lb | (tx << 10) | wflags, list_cnt, list_off);
 }
 
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
@@ -1766,7 +1767,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
   if (tile_has_owner && lane == 0 && wave == 0)
-    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, lp_mode ? WORK_LP : 0u, cnt, off);
+    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, lb, (uint32_t)tx0 / TILE, lp_mode ? WORK_LP : 0u, cnt, off);
 }
 
 // ================================================================================================================
@@ -1972,7 +1973,7 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
         const int ly = it * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
         ids_store4(slot, (uint32_t)(ly * TILE + lx4), *reinterpret_cast<const uint4 *>(&il[ly * LDS_STRIDE + lx4]), false);
       }
-      if (lane == 0) work_append(a, fd->flags, frame, entry, 0u, 0u, 0u);
+      if (lane == 0) work_append(a, fd->flags, frame, entry, lb, (uint32_t)tx0 / TILE, 0u, 0u, 0u);
     }
     __builtin_amdgcn_wave_barrier(); // the planes are reused by this wave's next tile
   }
@@ -2102,15 +2103,19 @@ void k_shade(RenderArgs a) {
     //         under the frame descriptor's scalar loads), and the indices of the list entries whose pieces it will stage
     const int ly = wave * 8 + (lane >> 3), lx4 = (lane & 7) * 4;
     const int p0 = ly * TILE + lx4;
-    // (raw: the 16-bit codes are classified as they are — position | 0x8000 for the S class, 0xffff = nobody —, never widened)
-    uint4 id4 = make_uint4(0u, 0u, 0u, 0u);
+    // (the 16-bit codes are classified as they are — position | 0x8000 for the S class, 0xffff = nobody —, never widened; and they
+    // are taken apart only at the classification below: unpacked here, the wait for this load would sit in front of the index
+    // loads that follow, one more round trip in a row per tile)
+    const uint32_t f = x.x, lb = x.y & 1023u, tx = (x.y >> 10) & 1023u;
+    const uint32_t tile_slot = f * tpf + lb * ap->tiles_x + tx;
+    uint4 id_raw = make_uint4(0u, 0u, 0u, 0u);
     {
-      const uint32_t *slot = ap->vis + (size_t)x.x * PIX_SLOT;
+      const uint32_t *slot = ap->vis + (size_t)tile_slot * PIX_SLOT;
       if (by_lp) {
         const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint16_t *>(slot) + p0);
-        id4 = make_uint4(w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16);
+        id_raw.x = w.x, id_raw.y = w.y;
       } else {
-        id4 = *reinterpret_cast<const uint4 *>(slot + p0);
+        id_raw = *reinterpret_cast<const uint4 *>(slot + p0);
       }
     }
     const uint32_t none = by_lp ? 0xffffu : NO_TRI, sbit = by_lp ? 0x8000u : S_CLASS_BIT; // (scalar)
@@ -2125,8 +2130,6 @@ void k_shade(RenderArgs a) {
         if (pc < n_pc) ti[k] = tlist[pc / 6u];
       }
     }
-    const uint32_t f = x.x / tpf, e = x.x % tpf;
-    const uint32_t tx = e % ap->tiles_x, lb = e / ap->tiles_x;
     const SRZ_CAS FrameDesc *fd = as_const(ap->frames) + f;
     const int W = fd->width, H = fd->height;
     const uint32_t tri_off = fd->tri_off, batch_off = fd->batch_off;
@@ -2144,11 +2147,14 @@ void k_shade(RenderArgs a) {
     const size_t row0 = (size_t)lb * BAND;
     float *out0 = ap->out + (size_t)f * ap->frame_stride + row0 * (size_t)W;
 
-    if (sd_staged && (uint32_t)tid < fd->n_batches) {
+    // (the frame's shader descriptors: loaded here, parked in LDS behind the first barrier — the store's wait for the load would
+    // otherwise hold wave 0, and with it the barrier, until this load, the last one issued, is back)
+    const bool sd_mine = sd_staged && (uint32_t)tid < fd->n_batches;
+    ShadeDescG sd_reg;
+    sd_reg.shader = 0, sd_reg.tw = sd_reg.th = 1, sd_reg._pad = 0, sd_reg.tex = nullptr;
+    if (sd_mine) {
       const SRZ_CAS ShadeDescG *g = sdesc + tid;
-      ShadeDescG d;
-      d.shader = g->shader, d.tw = g->tw, d.th = g->th, d._pad = 0, d.tex = g->tex;
-      s_sd[tid] = d;
+      sd_reg.shader = g->shader, sd_reg.tw = g->tw, sd_reg.th = g->th, sd_reg.tex = g->tex;
     }
 
     // ---- 2. the colour staging planes start as what the pixels this call does not own must hold: 0 after the fused clear, else
@@ -2175,7 +2181,8 @@ void k_shade(RenderArgs a) {
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
     *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
     // classify this thread's 4 pixels: per-thread counts, one packed wave scan (DPP), the waves' totals through LDS
-    const uint32_t idk[4] = {id4.x, id4.y, id4.z, id4.w};
+    uint32_t idk[4] = {id_raw.x, id_raw.y, id_raw.z, id_raw.w};
+    if (by_lp) idk[0] = id_raw.x & 0xffffu, idk[1] = id_raw.x >> 16, idk[2] = id_raw.y & 0xffffu, idk[3] = id_raw.y >> 16;
     uint32_t cnt2 = 0; // V count | S count << 16 of this thread
 #pragma unroll
     for (int k = 0; k < 4; ++k) cnt2 += idk[k] == none ? 0u : ((idk[k] & sbit) ? 0x10000u : 1u);
@@ -2208,6 +2215,7 @@ void k_shade(RenderArgs a) {
       bV += w2 < wave ? (t2 & 0xffffu) : 0u, bS += w2 < wave ? (t2 >> 16) : 0u, nV += t2 & 0xffffu, nS += t2 >> 16;
     }
     nV = (uint32_t)__builtin_amdgcn_readfirstlane((int)nV), nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)nS);
+    if (sd_mine) s_sd[tid] = sd_reg;
     uint32_t *const s_ent2 = reinterpret_cast<uint32_t *>(s_tri); // ({pixel, index} pairs: tiles without staged triangles)
     {
       uint32_t oV = bV + ((incl2 - cnt2) & 0xffffu), oS = nV + bS + ((incl2 - cnt2) >> 16);
