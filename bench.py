@@ -568,7 +568,7 @@ def multi_gpu_budget(args, world, wl_name):
     shard_bgr8 = n_frames * 3 * lay["local_rows"] * wl.width
     planes_case = 2 * shard_planes                                   # Case.out (n_out = 2): the rank's own float planes
     peak = planes_case + max(2 * world * shard_bgr8, 2 * world * shard_planes)
-    inputs = n_frames * (wl.frame(0).n_tris * (96 + 48 + 8 + 2 + 40) + 8 * lay["local_rows"] * wl.width)  # streams, PrepTri, boxes, entries, lists
+    inputs = n_frames * (wl.frame(0).n_tris * (96 + 36 + 8 + 2 + 40) + 8 * lay["local_rows"] * wl.width)  # records, dense positions, boxes, entries, lists
     return {"frames_per_step": n_frames, "shard_bytes_planes": shard_planes, "shard_bytes_bgr8": shard_bgr8,
             "gathered_buffers_bytes_planes": 2 * world * shard_planes, "gathered_buffers_bytes_bgr8": 2 * world * shard_bgr8,
             "peak_bytes_estimate": peak + inputs, "hbm_bytes": HBM_BYTES}

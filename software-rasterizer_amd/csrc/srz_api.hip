@@ -91,7 +91,9 @@ struct srz_frameset {
   std::vector<BatchDesc> h_batches;
   std::vector<ShadeDescG> h_sdesc;
   FrameDesc *d_frames = nullptr;
-  srz_tri *d_tris = nullptr;
+  srz_tri *d_tris = nullptr;     // the triangle stream as uploaded
+  float *d_tri_pos = nullptr;    // dense copy of its positions (9 floats per triangle); null: srz_draw's one-frame set, re-uploaded per call
+  bool tris_aos = false;
   BBox *d_bbox = nullptr;
   uint16_t *d_tri_batch = nullptr;
   BatchDesc *d_batches = nullptr;
@@ -100,7 +102,6 @@ struct srz_frameset {
   // it asked of each sub-pool (h_pool_heads: mapped host memory the device stores into), and a render that finds the previous demand
   // above the capacity grows the pool first — so the memory is O(triangle-tile pairs), not O(bands x triangles)
   uint32_t *d_pool = nullptr; // tile lists: triangle indices
-  PrepTri *d_prep = nullptr;
   uint32_t pool_sub_cap = 0, pool_n_sub = 1;
   bool pool_sized = false; // the first render has sized the pool by its own demand (render_impl)
   uint32_t *d_pool_heads = nullptr, *h_pool_heads = nullptr;
@@ -206,12 +207,12 @@ void free_frameset_buffers(srz_frameset *fs) {
   }
   (void)hipFree(fs->d_frames);
   (void)hipFree(fs->d_tris);
+  (void)hipFree(fs->d_tri_pos);
   (void)hipFree(fs->d_bbox);
   (void)hipFree(fs->d_tri_batch);
   (void)hipFree(fs->d_batches);
   (void)hipFree(fs->d_lights);
   (void)hipFree(fs->d_pool);
-  (void)hipFree(fs->d_prep);
   (void)hipFree(fs->d_pool_heads);
   if (fs->h_pool_heads) (void)hipHostFree(fs->h_pool_heads);
   (void)hipFree(fs->d_tile_info);
@@ -232,6 +233,8 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   RenderArgs a{};
   a.frames = fs->d_frames;
   a.tris = fs->d_tris;
+  a.tri_pos = fs->d_tri_pos ? fs->d_tri_pos : reinterpret_cast<const float *>(fs->d_tris);
+  a.pos_stride = fs->d_tri_pos ? TRI_POS_F : TRI_AOS_F;
   a.bbox = fs->d_bbox;
   a.chunk_rows = fs->d_chunk_rows;
   a.band_desc = fs->d_band_desc;
@@ -241,7 +244,6 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.lights = fs->d_lights;
   a.tex = ctx->d_tex;
   a.pool = fs->d_pool;
-  a.prep = fs->d_prep;
   a.pool_heads = fs->d_pool_heads;
   a.pool_demand = fs->h_pool_heads; // (hipHostMallocMapped: the same address on the device)
   a.pool_sub_cap = fs->pool_sub_cap;
@@ -386,7 +388,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // vertex stage on the device; outside counting runs it does the triangles' setup too (cull + bounding box from the registers
   // that hold the transformed triangle), and k_chunks replaces k_setup below
   const bool vertex_setup = fs->d_draws != nullptr && !stats;
-  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, fs->d_frames, vertex_setup ? fs->d_bbox : nullptr, fs->d_prep, s);
+  if (fs->d_draws) launch_vertex(fs->d_draws, fs->n_draws, fs->max_faces, fs->d_tris, fs->d_tri_pos, fs->d_frames, vertex_setup ? fs->d_bbox : nullptr, s);
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in the rasteriser (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
@@ -652,7 +654,7 @@ int srz_texture_upload(srz_ctx *ctx, int tex_id, const uint8_t *bgr, int w, int 
   return SRZ_OK;
 }
 
-static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out, bool copy_tris) {
+static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out, bool copy_tris, bool tris_aos = false) {
   if (!ctx) return SRZ_E_INVALID;
   if (!out) return fail(ctx, SRZ_E_INVALID, "srz_frameset_create: out is NULL");
   *out = nullptr;
@@ -713,7 +715,9 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   classify_frames(fs);
 
   // stage host copies (pinned not needed: one-time upload)
+  fs->tris_aos = tris_aos && copy_tris;
   std::vector<srz_tri> h_tris(copy_tris ? (size_t)tri_off : 0);
+  std::vector<float> h_pos(copy_tris && !fs->tris_aos ? (size_t)tri_off * TRI_POS_F : 0); // the dense copy of the positions
   std::vector<uint16_t> h_tb((size_t)tri_off);
   std::vector<srz_light> h_lights((size_t)light_off);
   for (int f = 0; f < n_frames; ++f) {
@@ -722,7 +726,11 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     size_t o = d.tri_off;
     for (uint32_t b = 0; b < fr.n_batches; ++b) {
       const srz_batch &sb = fr.batches[b];
-      if (copy_tris && sb.n_tris) std::memcpy(&h_tris[o], sb.tris, sizeof(srz_tri) * sb.n_tris);
+      if (copy_tris && sb.n_tris) {
+        std::memcpy(&h_tris[o], sb.tris, sizeof(srz_tri) * sb.n_tris);
+        if (!h_pos.empty())
+          for (size_t t = 0; t < sb.n_tris; ++t) std::memcpy(&h_pos[(o + t) * TRI_POS_F], &sb.tris[t].pos[0][0], sizeof(float) * TRI_POS_F);
+      }
       std::fill(h_tb.begin() + o, h_tb.begin() + o + sb.n_tris, (uint16_t)b);
       o += sb.n_tris;
     }
@@ -734,6 +742,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   if (e == hipSuccess) e = (expr)
   FS_TRY(dev_alloc((void **)&fs->d_frames, sizeof(FrameDesc) * n_frames));
   FS_TRY(dev_alloc((void **)&fs->d_tris, sizeof(srz_tri) * tri_off));
+  if (!fs->tris_aos) FS_TRY(dev_alloc((void **)&fs->d_tri_pos, sizeof(float) * TRI_POS_F * tri_off + 16)); // (+16: the last triangle's 9 floats are read as 4 + 4 + 1)
   FS_TRY(dev_alloc((void **)&fs->d_bbox, sizeof(BBox) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_chunk_rows, sizeof(uint32_t) * (tri_off / 64 + (size_t)n_frames + 1)));
   FS_TRY(dev_alloc((void **)&fs->d_band_desc, sizeof(uint32_t) * group_off * fs->n_local_bands));
@@ -751,7 +760,6 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     const uint64_t cap = std::min<uint64_t>((4ull * tri_off + 4096u) / n_sub + 64u, 0xfffffff0ull / n_sub);
     fs->pool_sub_cap = (uint32_t)cap;
     FS_TRY(dev_alloc((void **)&fs->d_pool, sizeof(uint32_t) * cap * n_sub));
-    FS_TRY(dev_alloc((void **)&fs->d_prep, sizeof(PrepTri) * tri_off));
     FS_TRY(dev_alloc((void **)&fs->d_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64)); // (one cache line per allocator)
     // what a render asked of each sub-pool comes back through pinned, device-mapped host memory: small jobs store it from
     // k_raster's first workgroup (no copy, no event, no query on the launch path), batches copy it on the clear's side stream
@@ -769,6 +777,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
   if (tri_off) {
     if (copy_tris) FS_TRY(hipMemcpy(fs->d_tris, h_tris.data(), sizeof(srz_tri) * tri_off, hipMemcpyHostToDevice));
+    if (!h_pos.empty()) FS_TRY(hipMemcpy(fs->d_tri_pos, h_pos.data(), sizeof(float) * h_pos.size(), hipMemcpyHostToDevice));
     FS_TRY(hipMemcpy(fs->d_tri_batch, h_tb.data(), sizeof(uint16_t) * tri_off, hipMemcpyHostToDevice));
   }
   if (!fs->h_batches.empty())
@@ -1458,7 +1467,7 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
     if (ctx->draw_fs) srz_frameset_destroy(ctx, ctx->draw_fs);
     (void)hipFree(ctx->draw_out);
     ctx->draw_fs = nullptr, ctx->draw_out = nullptr, ctx->draw_sig.clear();
-    rc = frame ? srz_frameset_create(ctx, frame, 1, &ctx->draw_fs) : srz_sceneset_create(ctx, scene, 1, &ctx->draw_fs);
+    rc = frame ? build_frameset(ctx, frame, 1, &ctx->draw_fs, true, /*tris_aos=*/true) : srz_sceneset_create(ctx, scene, 1, &ctx->draw_fs);
     if (rc) return rc;
     if (hipMalloc(&ctx->draw_out, 4 * (size_t)W * H * sizeof(float)) != hipSuccess) {
       srz_frameset_destroy(ctx, ctx->draw_fs);

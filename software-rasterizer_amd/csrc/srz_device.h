@@ -54,18 +54,16 @@ struct __attribute__((aligned(8))) BBox {
   int16_t sx, sy, ex, ey;
 };
 
-// What the rasteriser needs of one kept triangle: screen-space positions + bounding box, 48 bytes = three 16-byte loads.
-// Written ONCE per triangle by k_setup (or k_vertex) at prep[triangle]; a TILE's list holds 4-byte triangle indices and the
-// tile's wave gathers the records through them (the lists used to hold whole 48-byte records: 12x the bytes per
-// (triangle, tile) pair, scattered stores that were half of k_bin's time).
-struct __attribute__((aligned(16))) PrepTri {
-  float ax, ay, z0, bx, by, z1, cx, cy, z2;
-  uint32_t bbx; // sx | sy << 16
-  uint32_t bby; // ex | ey << 16
-  uint32_t _pad;
-};
+// The triangle stream in HBM: the boundary's 96-byte srz_tri records (36 bytes of positions, 60 of normals + texture
+// coordinates) as uploaded — what k_shade stages per tile — plus a DENSE COPY OF THE POSITIONS, 9 floats per triangle, made at
+// upload (or written by k_vertex beside the record).  k_setup streams the dense copy (36 bytes per triangle instead of the 96
+// its cache lines used to drag in) and k_raster gathers a tile's triangles from it through the 4-byte indices of the tile's list,
+// the bounding box from bbox[] (8 bytes): there is no per-triangle record written by k_setup any more (it was 48 bytes written
+// per kept triangle, every frame).  The kernels address triangle i's positions at tri_pos + i * pos_stride; srz_draw, which
+// re-uploads one frame's records per call, makes no copy: tri_pos = the records themselves, pos_stride = 24.
 // (the per-triangle constants of the coverage tests — 1 / fmsub(ABx,ACy,ACx*ABy) for the V columns, ABx*ACy - ABy*ACx for the
 // S columns — are recomputed by k_raster from the positions, once per list entry and 64 entries at a time)
+constexpr uint32_t TRI_POS_F = 9, TRI_AOS_F = 24; // floats
 
 // What the Shader object bound to a batch holds (type + texture), resolved on the host at render time
 struct __attribute__((aligned(8))) ShadeDescG {
@@ -115,7 +113,9 @@ enum { ST_TRIS = 0, ST_CULLED, ST_PIXEL_TESTS, ST_FRAGMENTS, ST_SHADED, ST_VISIB
 
 struct RenderArgs {
   const FrameDesc *frames;
-  const srz_tri *tris;
+  const srz_tri *tris;           // the records (k_shade)
+  const float *tri_pos;          // [triangle * pos_stride]: ax ay z0 bx by z1 cx cy z2 (k_setup, k_raster)
+  uint32_t pos_stride;           // floats: 9 (the dense copy) or 24 (the records themselves)
   const BBox *bbox;
   uint32_t *chunk_rows;          // per 64-triangle chunk: min sy | max ey << 16 of its kept triangles (k_setup → k_bands)
   uint32_t *band_desc;           // [group][n_local_bands]: first entry << 16 | entries of the group in that band, or DESC_RAW
@@ -125,7 +125,6 @@ struct RenderArgs {
   const srz_light *lights;
   const TexDesc *tex;
   const ShadeDescG *sdesc;       // per batch (indexed like batches[])
-  PrepTri *prep;                 // [triangle] (indexed like tris[]): positions + bbox of the kept triangles
   // per-tile triangle lists, UNORDERED (the rasteriser's result does not depend on list order): triangle indices in a pool
   // of n_sub equal sub-pools with one bump allocator each; a (frame, band) workgroup of k_bin takes its band's entries
   // from sub-pool (workgroup id & sub_mask) in one allocation.  A band that does not fit is left UNLISTED: its tiles are
@@ -165,8 +164,8 @@ struct RenderArgs {
   unsigned long long *timeline; // diagnostic (STATS variant only): per tile {start, end (wall clock 100 MHz), hw_id, blocks}
 };
 
-void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out,
-                   PrepTri *prep, hipStream_t s);
+void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, float *tri_pos, const FrameDesc *frames,
+                   BBox *bbox_out, hipStream_t s);
 void launch_chunks(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool stats, hipStream_t s);
 void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);

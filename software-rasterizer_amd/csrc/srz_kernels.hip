@@ -5,9 +5,10 @@
 // Not a translation of the AVX2 code: the reference walks triangles serially and rows in parallel; here
 //
 //   k_vertex  one thread per face          (optional) the vertex stage, Scene::loadTriangleStream: meshes + matrices → srz_tri
-//   k_setup   one thread per triangle      bbox (Triangle::calcBoundingBox) + backface test → 8-byte BBox, the 48-byte PrepTri
-//                                          (positions + bbox) of every kept triangle, and — per group of 512 triangles, in
-//                                          LDS — the triangles sorted by the 32-row bands they reach: binning is O(triangles)
+//                                          + the dense copy of its positions
+//   k_setup   one thread per triangle      reads the dense positions (36 bytes): bbox (Triangle::calcBoundingBox) + backface
+//                                          test → 8-byte BBox, and — per group of 512 triangles, in LDS — the triangles
+//                                          sorted by the 32-row bands they reach: binning is O(triangles)
 //   k_bin     one WORKGROUP per 32-row band count / scan / fill of the band's own entries into UNORDERED per-tile lists of 4-byte
 //                                          triangle indices, LDS atomics only, assembled in LDS and stored as one coalesced run;
 //                                          the lists come from a pool sized by what renders need
@@ -398,19 +399,21 @@ __device__ __forceinline__ bool setup_triangle(const float (&P)[9], int W, int H
   return keep;
 }
 
-// What the rasteriser needs of a kept triangle, written ONCE per triangle (48 bytes, coalesced) by the kernel that has its
-// positions in registers (k_setup, or k_vertex for scenesets); the tile lists hold 4-byte indices into this array.
-__device__ __forceinline__ void prep_store(PrepTri *dst, const float (&P)[9], const BBox &bb) {
-  const f32x4 q0 = {P[0], P[1], P[2], P[3]}, q1 = {P[4], P[5], P[6], P[7]};
-  const f32x4 q2 = {P[8], u2f_((uint32_t)(uint16_t)bb.sx | ((uint32_t)(uint16_t)bb.sy << 16)),
-                    u2f_((uint32_t)(uint16_t)bb.ex | ((uint32_t)(uint16_t)bb.ey << 16)), 0.0f};
-  f32x4 *o = reinterpret_cast<f32x4 *>(dst);
-  o[0] = q0, o[1] = q1, o[2] = q2;
+// A 12-byte piece of the dense position stream (9 floats per triangle, srz_device.h), moved three floats at a time
+// (global_load_dwordx3 / global_store_dwordx3 or wider: dword alignment is all they need)
+struct F3 {
+  float x, y, z;
+};
+__device__ __forceinline__ F3 ld3(const SRZ_CAS float *p) { return F3{p[0], p[1], p[2]}; } // (one global_load_dwordx3)
+// the 9 position floats of triangle i (ax ay z0 bx by z1 cx cy z2)
+__device__ __forceinline__ void load_pos9(const SRZ_CAS float *p, float (&P)[9]) {
+  const F3 v0 = ld3(p), v1 = ld3(p + 3), v2 = ld3(p + 6);
+  P[0] = v0.x, P[1] = v0.y, P[2] = v0.z, P[3] = v1.x, P[4] = v1.y, P[5] = v1.z, P[6] = v2.x, P[7] = v2.y, P[8] = v2.z;
 }
 
 // (bbox_out != null: the triangle's setup — cull + bounding box — is done here too, from the registers that hold it; k_chunks
 // then only reduces the boxes to the chunks' row ranges and the 96-byte triangles are not read back by a k_setup)
-__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out, PrepTri *prep) {
+__global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *tris, float *tri_pos, const FrameDesc *frames, BBox *bbox_out) {
   const SRZ_CAS DrawDesc *d = as_const(draws) + blockIdx.y;
   const uint32_t n_faces = d->n_faces;
   const SRZ_CAS srz_vertex *verts = as_const(d->verts);
@@ -429,13 +432,16 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawDesc *draws, srz_tri *
       t.nrm[k][0] = x, t.nrm[k][1] = y, t.nrm[k][2] = z;
       t.uv[k][0] = v->uv[0], t.uv[k][1] = v->uv[1];
     }
-    tris[d->tri_off + f] = t;
+    const size_t ti = (size_t)d->tri_off + f;
+    tris[ti] = t;
+    const float P[9] = {t.pos[0][0], t.pos[0][1], t.pos[0][2], t.pos[1][0], t.pos[1][1], t.pos[1][2], t.pos[2][0], t.pos[2][1], t.pos[2][2]};
+    F3 *po = reinterpret_cast<F3 *>(tri_pos + ti * TRI_POS_F); // (the dense copy of the positions: what k_setup and k_raster read)
+    po[0] = F3{P[0], P[1], P[2]}, po[1] = F3{P[3], P[4], P[5]}, po[2] = F3{P[6], P[7], P[8]};
     if (bbox_out) {
       const SRZ_CAS FrameDesc *fd = as_const(frames) + d->frame;
-      const float P[9] = {t.pos[0][0], t.pos[0][1], t.pos[0][2], t.pos[1][0], t.pos[1][1], t.pos[1][2], t.pos[2][0], t.pos[2][1], t.pos[2][2]};
       BBox bb;
-      if (setup_triangle(P, fd->width, fd->height, fd->eye[0], fd->eye[1], fd->eye[2], true, bb)) prep_store(prep + d->tri_off + f, P, bb);
-      bbox_out[d->tri_off + f] = bb;
+      (void)setup_triangle(P, fd->width, fd->height, fd->eye[0], fd->eye[1], fd->eye[2], true, bb);
+      bbox_out[ti] = bb;
     }
   }
 }
@@ -638,9 +644,7 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
 #pragma unroll
     for (int k = 0; k < (int)GROUP_K; ++k) { // (all the loads of the thread's triangles in flight together)
       const uint32_t t = t0 + (uint32_t)k * 256u + threadIdx.x;
-      const SRZ_CAS float *p = as_const(&a.tris[tri_off + (t < n_tris ? t : 0u)].pos[0][0]);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) P[k][i] = p[i];
+      load_pos9(as_const(a.tri_pos) + (size_t)(tri_off + (t < n_tris ? t : 0u)) * a.pos_stride, P[k]);
     }
     BBox bb[GROUP_K];
     bool keep[GROUP_K];
@@ -656,7 +660,6 @@ __global__ __launch_bounds__(256) void k_setup(RenderArgs a, BBox *bbox_out) {
           n_culled++;
       }
       if (live) bbox_out[tri_off + t] = bb[k];
-      if (keep[k]) prep_store(a.prep + tri_off + t, P[k], bb[k]);
       chunk_rows_store(a, fd->chunk_off, t, n_tris, keep[k], bb[k]);
     }
     bucket_group(a, fd->n_local_bands, fd->group_off + g, t0, (fd->flags & FD_PACKED) != 0u, tri_off, bb, keep, P, s_cnt, s_off, s_fill, s_misc);
@@ -710,8 +713,8 @@ __global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
 //   scan    exclusive prefix over the tile counters (wave 0) = the band's layout; ONE global atomic takes the band's
 //           records from the sub-pool of this workgroup (k_raster_slow serves the tiles of a band that does not fit)
 //   pass 2  every (triangle, tile) pair becomes one 4-byte index at pool[band base + tile offset + slot]: assembled in LDS,
-//           written as one coalesced run (k_raster gathers the triangles' 48-byte PrepTri records, written once per triangle
-//           by k_setup / k_vertex, through these indices)
+//           written as one coalesced run (k_raster gathers the triangles' 36 bytes of positions and their 8-byte boxes
+//           through these indices)
 // ================================================================================================================
 constexpr int BIN_MAX_WAVES = 8; // launched with 2, 4 or 8 waves: the walk is latency-bound, so short streams take small
                                  // workgroups (more of them resident per CU), long ones more waves per band
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   }
   if (base == UNLISTED || s_misc[1] == 0u) return; // workgroup-uniform
   // ---- pass 2: fill ------------------------------------------------------------------------------------------------------
-  // The band's lists hold 4-byte triangle indices (the rasteriser gathers the 48-byte PrepTri of an index itself): they are
+  // The band's lists hold 4-byte triangle indices (the rasteriser gathers the positions of an index itself): they are
   // assembled in LDS — slots handed out by LDS atomics, tile after tile — and leave as ONE run of coalesced stores.  A band
   // with more pairs than the stage holds stores its indices straight into the pool.
   uint32_t *out = a.pool + base;
@@ -1515,7 +1518,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     return g;
   };
   const SRZ_CAS uint32_t *list = as_const(a.pool) + off; // the tile's triangle indices
-  const SRZ_CAS f32x4 *prep = reinterpret_cast<const SRZ_CAS f32x4 *>(as_const(a.prep) + fd->tri_off);
+  // a list entry's record: the triangle's 9 position floats from the dense stream + its 8-byte bounding box (four independent loads)
+  const SRZ_CAS float *tpos = as_const(a.tri_pos) + (size_t)fd->tri_off * a.pos_stride;
+  const SRZ_CAS u32x2 *tbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
+  const uint32_t pos_stride = a.pos_stride;
+  auto rec_load = [&](uint32_t i, f32x4 &q0, f32x4 &q1, f32x4 &q2) { // q0 = ax ay z0 bx | q1 = by z1 cx cy | q2 = z2 bbx bby -
+    const SRZ_CAS float *q = tpos + (size_t)i * pos_stride;
+    const F3 v0 = ld3(q), v1 = ld3(q + 3), v2 = ld3(q + 6);
+    const u32x2 bb = tbox[i];
+    q0 = f32x4{v0.x, v0.y, v0.z, v1.x}, q1 = f32x4{v1.y, v1.z, v2.x, v2.y}, q2 = f32x4{v2.z, u2f_(bb.x), u2f_(bb.y), 0.0f};
+  };
   // ---- depth-ordered groups for chunks with heavy overdraw -----------------------------------------------------------
   // The keys make the order of the triangles irrelevant, so a chunk of records that asks for several times the tile's area in
   // pixel tests is rasterised NEAREST FIRST, in 4 groups of equal depth range of the triangles' nearest vertex (the records
@@ -1533,11 +1545,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   f32x4 n0, n1, n2;
   bool nv = (uint32_t)lane < cnt;
   uint32_t i_cur = i_first, i_nxt = 64u < cnt ? (list[min(64u + (uint32_t)lane, cnt - 1u)] & idx_mask) : 0u;
-  n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
+  rec_load(i_cur, n0, n1, n2);
   for (uint32_t base = 0; base < cnt; base += 64) {
     const f32x4 r0 = n0, r1 = n1, r2 = n2;
     const uint32_t my_idx = lp_mode ? ((i_cur << LP_BITS) | (base + (uint32_t)lane)) : i_cur; // (the tie-break's payload)
-    // the per-triangle constants of the two coverage tests, once per record (a record carries 48 bytes, not these 8 more)
+    // the per-triangle constants of the two coverage tests, once per record (not stored anywhere: 8 bytes more per triangle to write and to gather)
     float rec_v_inv, rec_s_area;
     {
       TriXY k;
@@ -1550,7 +1562,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     nv = base + 64 + lane < cnt;
     if (base + 64 < cnt) {
       i_cur = i_nxt;
-      n0 = prep[3 * i_cur], n1 = prep[3 * i_cur + 1], n2 = prep[3 * i_cur + 2];
+      rec_load(i_cur, n0, n1, n2);
       if (base + 128 < cnt) i_nxt = list[min(base + 128u + (uint32_t)lane, cnt - 1u)] & idx_mask;
     }
     const Geo G = geometry(r0, r1, r2, rec_s_area, valid);
@@ -1812,7 +1824,7 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
     __builtin_amdgcn_wave_barrier();
     // ---- phase B: the frame's triangles in submission order ------------------------------------------------------
     const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
-    const SRZ_CAS srz_tri *tris = as_const(a.tris) + fd->tri_off;
+    const SRZ_CAS float *tpos = as_const(a.tri_pos) + (size_t)fd->tri_off * a.pos_stride;
     const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->chunk_off;
     const uint32_t n_chunks = (n_tris + 63) / 64;
     for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -1832,7 +1844,8 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
       //   whichever needs the fewest blocks)
       uint32_t geom = 0;
       if (hit) {
-        const SRZ_CAS float *p = &tris[my].pos[0][0];
+        float p[9];
+        load_pos9(tpos + (size_t)my * a.pos_stride, p);
         t.ax = p[0], t.ay = p[1], t.z0 = p[2], t.bx = p[3], t.by = p[4], t.z1 = p[5], t.cx = p[6], t.cy = p[7], t.z2 = p[8];
         BranchMath bm;
         tri_consts(bm, t);
@@ -2077,7 +2090,6 @@ void k_shade(RenderArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long n_vis = 0, n_vis_tex = 0;
-  const uint32_t tpf = a.n_local_bands * a.tiles_x;
 
   // ---- one owned tile: x = its work-list entry (work_append).  mode: 0 = FAST variants, 1 = generic (FastMath, then IEEE if
   //      needed), 2 = IEEE at once -------------------------------------------------------------------------------------------------
@@ -2607,12 +2619,12 @@ __global__ void k_tex_convert(const uint8_t *bgr, int w, int h, int row_stride, 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, const FrameDesc *frames, BBox *bbox_out,
-                   PrepTri *prep, hipStream_t s) {
+void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, float *tri_pos, const FrameDesc *frames,
+                   BBox *bbox_out, hipStream_t s) {
   if (n_draws == 0 || max_faces == 0) return;
   dim3 grid((max_faces + 255) / 256, n_draws);
   if (grid.x > 1024) grid.x = 1024;
-  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris, frames, bbox_out, prep);
+  hipLaunchKernelGGL(k_vertex, grid, dim3(256), 0, s, draws, tris, tri_pos, frames, bbox_out);
 }
 
 void launch_chunks(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s) {
