@@ -56,16 +56,31 @@ PRIME_TO = 20      # untimed renders in front of every timed region, the --warmu
 
 
 def kernel_source_hash():
-    """sha256 of the built library that RUNS (software-rasterizer_amd/libsrz.so: kernels + C ABI), first 16 hex digits:
-    profiles/summarize.py stores it in profiles/pmc_counters.json next to the counters it collected with that library, and a
-    bench line of ANOTHER build reports traffic: null + traffic_stale instead of another code version's counters.  (The binary,
-    not the source text: a comment edit does not invalidate a profile, a flag or toolchain change does.)"""
+    """sha256 of the DEVICE CODE of the library that runs (the .hip_fatbin section of software-rasterizer_amd/libsrz.so: every
+    kernel as compiled for gfx950), first 16 hex digits: bench.py writes it into its line, profiles/summarize.py stores the one
+    of the profiled run in profiles/pmc_counters.json next to the counters, and a bench line of a build with OTHER kernels reports
+    traffic: null + traffic_stale instead of another code version's counters.  (The compiled kernels, not the source text and
+    not the host code around them: a comment or a host-side edit does not invalidate a profile; a kernel, flag or compiler
+    change does.)"""
     import hashlib
+    import struct
     lib = os.environ.get("SRZ_LIB_PATH", os.path.join(REPO, "software-rasterizer_amd", "libsrz.so"))
     try:
-        return hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+        b = open(lib, "rb").read()
     except OSError:
         return "no-library"
+    try:  # ELF64 little-endian section walk
+        shoff, = struct.unpack_from("<Q", b, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+        sec = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+        str_off = sec[shstrndx][4]
+        for name, _t, _f, _a, off, size, *_ in sec:
+            end = b.index(b"\0", str_off + name)
+            if b[str_off + name:end] == b".hip_fatbin":
+                return "fb-" + hashlib.sha256(b[off:off + size]).hexdigest()[:16]
+    except (struct.error, ValueError, IndexError):
+        pass
+    return hashlib.sha256(b).hexdigest()[:16]  # (no such section: the whole file)
 
 
 def launch_ranks(n_ranks, argv):

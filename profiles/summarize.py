@@ -124,7 +124,13 @@ for jf in sorted(glob.glob(os.path.join(src, "*.traced.json"))):
 # the counters describe THESE kernel sources: bench.py reports them only for a tree whose sources hash the same
 sys.path.insert(0, os.path.dirname(here))
 import bench  # noqa: E402
-counters["_kernel_source_hash"] = out["kernel_source_hash"] = bench.kernel_source_hash()
+# (the hash the PROFILED run reported on the box; an old collection without one: this tree's library)
+try:
+    _line = [l for l in open(os.path.join(src, "bench_plain.json")) if l.startswith('{"metric"')][-1]
+    _h = json.loads(_line)["roofline"].get("kernel_source_hash")
+except (OSError, IndexError, KeyError, ValueError):
+    _h = None
+counters["_kernel_source_hash"] = out["kernel_source_hash"] = _h or bench.kernel_source_hash()
 json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump(counters, open(counters_file, "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_plain.json"), os.path.join(here, f"{tag}_bench.json"))

@@ -59,6 +59,7 @@ struct srz_ctx {
   // default below), 32-bit owner ids even where 16 would do
   int env_sub_batch = 0;
   bool env_no_packed = false; // SRZ_NO_PACKED (tests): see srz_frameset::no_packed
+  bool env_no_turns = false;  // SRZ_NO_TURNS (A/B): renders on different streams do not wait for each other's k_raster
   bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
@@ -376,7 +377,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, s));
     HIP_TRY(ctx, hipMemsetAsync(fs->d_slow_count, 0, 2 * sizeof(uint32_t), s));
   }
-  const bool turns = !stats && fs->max_tiles >= 8192; // (batches; small jobs are launch-bound and gain nothing)
+  const bool turns = !stats && fs->max_tiles >= 8192 && !ctx->env_no_turns; // (batches; small jobs are launch-bound and gain nothing)
   if (turns) {
     if (!ctx->ev_raster[0])
       for (int i = 0; i < srz_ctx::EV_RING; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_raster[i], hipEventDisableTiming));
@@ -562,6 +563,7 @@ int srz_create(srz_ctx **out, int device_id) {
   ctx->device = device_id;
   ctx->env_sub_batch = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0;
   ctx->env_no_packed = getenv("SRZ_NO_PACKED") != nullptr;
+  ctx->env_no_turns = getenv("SRZ_NO_TURNS") != nullptr;
   ctx->opt_pool_lazy = getenv("SRZ_POOL_LAZY") != nullptr;
   for (int i = 0; i < MAX_TEX; ++i) ctx->h_tex[i] = TexDesc{nullptr, 0, 0}, ctx->d_texmem[i] = nullptr;
   auto bail = [&](const char *what, hipError_t err) {

@@ -44,10 +44,10 @@ def test_pmc_counters_are_tied_to_the_library_build(tmp_path, monkeypatch):
     sys.path.insert(0, REPO)
     import bench
     h = bench.kernel_source_hash()
-    assert len(h) == 16 and h == bench.kernel_source_hash()
+    assert h.startswith("fb-") and len(h) == 19 and h == bench.kernel_source_hash()  # (the library's .hip_fatbin section)
     monkeypatch.setattr(bench, "_PMC", {"_kernel_source_hash": h, "w": {"frames_per_step": 4, "hbm_bytes_per_step": 1.0}})
     assert not bench.pmc_stale() and bench.pmc_counters("w", 4, "raster")["hbm_bytes_per_step"] == 1.0
-    monkeypatch.setattr(bench, "_PMC", {"_kernel_source_hash": "0" * 16, "w": {"frames_per_step": 4, "hbm_bytes_per_step": 1.0}})
+    monkeypatch.setattr(bench, "_PMC", {"_kernel_source_hash": "fb-" + "0" * 16, "w": {"frames_per_step": 4, "hbm_bytes_per_step": 1.0}})
     assert bench.pmc_stale() and bench.pmc_counters("w", 4, "raster") is None
     # the committed file: either collected from this tree's sources, or reported as stale — never silently another version's
     monkeypatch.setattr(bench, "_PMC", None)
