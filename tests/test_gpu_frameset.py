@@ -48,6 +48,23 @@ def test_frameset_equals_per_frame_draw_and_oracle(orc, frames):
     ctx.close()
 
 
+def test_both_triangle_stream_layouts_give_the_same_planes(frames):
+    """a frameset keeps a dense copy of the positions for k_setup / k_raster (pos_stride 9); srz_draw re-uploads one frame's 96-byte
+    records per call and the same kernels read the positions out of them (pos_stride 24).  Same frame, both ways, bit for bit —
+    twice, so that the second srz_draw goes through the re-upload of an existing set"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    _, out = render(ctx, frames)
+    got = out.cpu().numpy()
+    for rep in range(2):
+        for i, f in enumerate(frames):
+            planes, _ = ctx.draw(f)
+            for p in range(4):
+                assert np.array_equal(bits(got[i, p]), bits(planes[p])), (rep, i, p)
+    ctx.close()
+
+
 def test_kernel_timing_api(frames):
     import srz
     ctx = srz.Context(0)
