@@ -18,13 +18,13 @@ N > 1: one process per GPU; every frame's 32-row bands are dealt round-robin to 
 renders its bands of F*N frames (per-GPU pixel work fixed → weak scaling), and the exchange north_star names — ONE in-place
 RCCL all-gather over xGMI behind the C ABI (srz_frameset_allgather_inplace) — reassembles every full framebuffer on every
 rank.  The exchange of step k runs on its own stream while step k+1 renders (double-buffered).
-WHAT is exchanged at N > 1 (decided and stated here): the headline (`value`) exchanges `bgr8` — the reference's
-final framebuffer IS the 8-bit image: display() merges the planes into m_frameBuffer and converts it to CV_8UC3 in place
-(src/Render.cpp:61-62) — i.e. every rank resolves its bands on the device (k_resolve8) and all-gathers 3 B/px; the same
-run then times the exchange of the four float planes (16 B/px: z + the three m_channels) and reports it beside the headline in
-`multi_gpu.planes`, with DESIGN.md §6's prediction for both in `multi_gpu.predicted`.
+WHAT is exchanged at N > 1: the headline (`value`) exchanges the four float planes (16 B/px: z + the three
+m_channels — what draw() leaves, and what north_star's parity is stated on: z bit-exact) at every N, so rounds compare; the same
+run then times the exchange of display()'s 8-bit image (src/Render.cpp:61-62: every rank resolves its bands on the device,
+k_resolve8, and all-gathers 3 B/px) and reports it beside the headline in `multi_gpu.bgr8`, never as `value`.
 
-Prints ONE JSON line (rank 0).  PyTorch is only plumbing here (device buffers, streams, the rendezvous).
+Prints ONE compact JSON line (rank 0) of < 6 KB as the LAST line of stdout; every note and the full per-workload records go to
+bench_details.json next to this script and to stderr (emit()).  PyTorch is only plumbing here (device buffers, streams, the rendezvous).
 """
 import argparse
 import json
@@ -50,6 +50,8 @@ EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 12
 
 # workloads whose summary goes into roofline.per_config (the part of the line the driver's parser keeps): BASELINE configs 3 / 4 / 5,
 # the scene of the reference's one published figure, configs[1] at scope draw, the exponent variant the generic build used to serve
+# (workload, frames per step, steps) rendered once more in the tolerance mode (SRZ_OPT_APPROX_SHADE): `<workload>:approx` rows
+APPROX_CASES = [("spot_texture_1024", 256, 10), ("spot_bunny_phong_1080p", 128, 10), ("spot_x8_overdraw_4096", 64, 10)]
 PER_CONFIG = ("spot_bunny_phong_1080p", "spot_x16_texture_2048", "spot_x8_overdraw_4096", "readme_spot_crate_1024", "spot_texture_1024_p7.5")
 HBM_BYTES = 288e9  # per MI355X
 PRIME_TO = 20      # untimed renders in front of every timed region, the --warmup steps included (time_single_gpu)
@@ -248,6 +250,8 @@ def cpu_baseline(workload_name, budget_s=12.0, max_frames=100000):
                                 for k, v in results.items()) +
                       f"; single-thread -O2 oracle: {1.0 / single:.1f} frames/s (rows = bands of 8 rows of one frame per thread, "
                       "frames = whole frames per thread; O2 = the checker's build, O3 = -O3 -mavx2 -mfma -ftree-vectorize)",
+            "sample_short": f"{workload_name}: clear+draw per frame, {results[best]['frames']} frames in {results[best]['seconds']:.1f} s on "
+                            f"{results[best]['threads']} threads ({best}: best of rows/frames x O2/O3, ~{budget_s:.0f} s in all); 1 thread: {1.0 / single:.1f} frames/s",
             "variants": {k: {"frames_per_sec": v["rate"], "threads": v["threads"]} for k, v in results.items()}}
 
 
@@ -305,7 +309,7 @@ class Case:
         self.torch.cuda.empty_cache()
 
 
-def time_single_gpu(case, steps, warmup, fence, lanes=2):
+def time_single_gpu(case, steps, warmup, fence, lanes=2, unprimed=False):
     """W warm-up steps, then EXACTLY K steps bracketed by fences.
 
     A step renders the whole batch: `lanes` runs of whole frames, each on a stream of its own (srz.parallel.LaneRenderer —
@@ -320,11 +324,28 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     if lanes <= 0:  # auto: two lanes when each still holds a batch (measured: +4..8 % at >= 64 frames per step, -2 % at 32)
         lanes = 2 if case.n_frames >= 64 else 1
     lr = case.lanes(lanes)
-    # priming (untimed, not counted as warm-up; reported as `priming_steps`): the first ~13 renders after idle run up to 10 % slower
-    # (clock ramp, first touch of the list pool: tools/step_series_probe.py prints the series) — a short --warmup would end inside
-    # that ramp and measure the ramp, not the pipeline.  PRIME_TO untimed renders in all are made sure of.
-    for _ in range(max(0, PRIME_TO - warmup)):
+    # priming (not counted as warm-up; reported as `priming_steps`): the first ~13 renders after idle run up to 10 % slower
+    # (clock ramp, first touch of the list pool: tools/step_series_probe.py prints the series) — a short --warmup ends inside
+    # that ramp.  The headline case therefore times TWO regions: first exactly what the arguments say from idle (W untimed steps,
+    # K timed: `value_unprimed` / `ms_per_step_unprimed`), then W more untimed steps and K timed ones in the steady state (`value`);
+    # the other workloads make sure of PRIME_TO untimed renders in all and time one region.
+    unprimed_dt = None
+    if unprimed:  # the driver's arguments taken literally: W untimed steps from idle, then K timed ones (`value_unprimed`); they
+        for _ in range(warmup):  # also serve as the priming of the region that follows
+            lr.render(out.data_ptr(), abi.FUSED_CLEAR)
+        fence()
+        tu = time.perf_counter()
+        for _ in range(steps):
+            lr.render(out.data_ptr(), abi.FUSED_CLEAR)
+        fence()
+        unprimed_dt = time.perf_counter() - tu
+        done = warmup + steps
+    else:
+        done = 0
+    extra = max(0, PRIME_TO - warmup - done)
+    for _ in range(extra):
         lr.render(out.data_ptr(), abi.FUSED_CLEAR)
+    priming = done + extra  # renders in front of the timed region beyond its own --warmup
     for _ in range(warmup):
         lr.render(out.data_ptr(), abi.FUSED_CLEAR)
     fence()
@@ -362,6 +383,7 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2):
     for k in ("bin_ms", "raster_ms", "shade_ms"):
         kt[k] = split[k]
     kt["split_total_ms"] = split["total_ms"]
+    kt["unprimed_dt"], kt["priming_steps"] = unprimed_dt, priming
     return dt, kt, per_step
 
 
@@ -572,6 +594,148 @@ def per_config_summary(rec):
                               "shade": r["one_stream"]["k_shade_ms"] * 1e3}}
 
 
+def emulate_shards(srz, torch, device, fence, args):
+    """The render-side term of the N-GPU job, measured on ONE GPU: for N in {2, 4, 8} this GPU plays every rank r
+    of N in turn (srz.Context(device, r, N): its 32-row bands of all F*N frames, one frameset on one stream as an N > 1 rank
+    renders them) and reports the per-rank render time, its imbalance, and the step an N-GPU job cannot beat:
+    max(slowest rank's render, shard bytes / 153 GB/s per xGMI link) for both exchanges.  F (frames per GPU) is smaller than
+    the headline's so that the fourteen + sixteen framesets stay cheap: every term scales with F, their ratios do not.
+    No multi-GPU run — nothing here claims one."""
+    from srz import abi, scenes
+    plan = [(args.workload, 32, (2, 4, 8)), ("spot_x16_texture_2048", 8, (8,)), ("spot_x8_overdraw_4096", 4, (8,))]
+    out = {}
+    stream = torch.cuda.Stream()
+    for (w, f_gpu, worlds) in plan:
+        wl = scenes.WORKLOADS[w]()
+        rec = {"frames_per_gpu": f_gpu}
+        for n in worlds:
+            n_frames = f_gpu * n
+            uniq = [wl.frame(i) for i in range(min(n_frames, 36))]
+            frames = [uniq[i % len(uniq)] for i in range(n_frames)]
+            ms = []
+            shard_bytes = 0
+            for r in range(n):
+                c = srz.Context(device, r, n)
+                wl.upload_textures(c)
+                fs = c.frameset(frames)
+                buf = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+                shard_bytes = fs.out_bytes
+                with torch.cuda.stream(stream):
+                    for _ in range(4):
+                        fs.render(buf.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+                    fence()
+                    c.set_kernel_timing(1)
+                    c.kernel_time_ms(reset=True)
+                    for _ in range(6):
+                        fs.render(buf.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
+                    fence()
+                    kt = c.kernel_time_ms(reset=True)
+                ms.append(kt["total_ms"])
+                fs.close()
+                c.close()
+                del buf
+            torch.cuda.empty_cache()
+            x_planes = shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+            x_bgr8 = x_planes * 3.0 / 16.0
+            rec[f"N{n}"] = {"shard_render_ms": ms, "max_over_mean": max(ms) / (sum(ms) / len(ms)),
+                            "predicted_step_ms": {"planes": max(max(ms), x_planes), "bgr8": max(max(ms), x_bgr8)},
+                            "predicted_fps": {"planes": n_frames / max(max(ms), x_planes) * 1e3, "bgr8": n_frames / max(max(ms), x_bgr8) * 1e3}}
+        out[w] = rec
+    return out
+
+
+def sig(x, n=4):
+    """floats to n significant digits (the line is for reading and for the driver's parser; the full precision is in the details file)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{n}g}")
+
+
+def compact(o, n=4):
+    if isinstance(o, dict):
+        return {k: compact(v, n) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, n) for v in o]
+    return sig(o, n)
+
+
+LINE_LIMIT = 6000  # bytes: the driver keeps 8 KB of stdout and parses the LAST line of it (round 4's 21 KB line came back parsed: null)
+DETAILS = os.path.join(REPO, "bench_details.json")
+SHORT = {"spot_bunny_phong_1080p": "c3", "spot_x16_texture_2048": "c4", "spot_x8_overdraw_4096": "c5", "readme_spot_crate_1024": "readme",
+         "spot_texture_1024_p7.5": "c2_p7.5", "spot_texture_1024": "c2"}
+
+
+def emit(res, extras):
+    """The full record (every note, every configs[] entry at full precision) goes to bench_details.json next to this script
+    (and, as one line, to stderr); stdout gets ONE compact JSON line of < LINE_LIMIT bytes as its LAST line: the contract's
+    keys, `roofline` (flat per-config scalars the driver's parser keeps + the nested per_config), `valu`, `cpu_baseline`."""
+    full = dict(res, configs=extras)
+    try:
+        with open(DETAILS, "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        pass
+    sys.stderr.write("bench.py details: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    roof = res["roofline"]
+    one = roof.get("one_stream") or {}
+    r = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "traffic_over_algorithmic",
+                                  "algorithmic_bytes_per_launch", "launch_ms", "lanes", "launches_timed", "kernel_source_hash")}
+    r["kernel"] = "k_setup+k_bin+k_raster+k_shade in line, k_clear beside them (second stream); HIP events on the launch streams"
+    r["frac_unprimed"] = (roof["algorithmic_bytes_per_launch"] / (res["ms_per_step_unprimed"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if res.get("ms_per_step_unprimed") else None
+    r["one_stream_us"] = [x * 1e3 if x is not None else None for x in (one.get("k_setup_bin_ms"), one.get("k_raster_ms"), one.get("k_shade_ms"))]
+    pc = {}
+    for name, v in (roof.get("per_config") or {}).items():
+        base, _, tag = name.partition(":")
+        key = SHORT.get(base, base) + (":" + tag if tag else "")
+        if "error" in v:
+            pc[key] = {"error": v["error"][:80]}
+        elif v.get("scope") == "readme_loop":
+            pc[key] = {"draw_ms_p10_med_p90": v["draw_complete_ms_p10_median_p90"], "display_ms": v["display_ms_median"], "frames": v["frames"],
+                       "ref_published_draw_ms": v["reference_published_draw_ms_median"]}
+        else:
+            pc[key] = {"F": v["frames_per_step"], "fps": v["frames_per_sec"], "ms": v["ms_per_step"], "frac": v["frac"],
+                       "t_over_a": v["traffic_over_algorithmic"], "us": [v["one_stream_us"][k] for k in ("setup_bin", "raster", "shade")]}
+            if not tag:  # flat scalars: the driver's parser keeps a nested object's scalars only
+                r["frac_" + key], r["fps_" + key] = v["frac"], v["frames_per_sec"]
+    r["per_config"] = pc
+    r["per_config_keys"] = "F frames/step, fps, ms/step (2 lanes), frac of 8 TB/s, traffic/algorithmic, us = one-stream [setup+bin, raster, shade]"
+    mg = roof.get("multi_gpu_emulated")
+    if mg is not None:
+        r["multi_gpu_emulated"] = mg if "error" in mg else {
+            SHORT.get(w, w): {k: (v if not isinstance(v, dict) else
+                                  {"ms": v["shard_render_ms"], "max_over_mean": v["max_over_mean"], "pred_ms": v["predicted_step_ms"], "pred_fps": v["predicted_fps"]})
+                              for k, v in rec.items()} for w, rec in mg.items()}
+    line = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    line["config"] = res["config"]
+    line.update({k: res.get(k) for k in ("priming_steps", "value_unprimed", "ms_per_step_unprimed", "mfragments_per_sec", "ms_per_step_p10_median_p90")})
+    line["roofline"] = r
+    v = res.get("valu")
+    line["valu"] = {k: v.get(k) for k in ("valu_frac", "valu_pipe_frac_est", "valu_per_64_visible_px")} if v else None
+    cb = res.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "shape", "cpu_model", "host_cpus")}
+        line["cpu_baseline"]["sample"] = (cb.get("sample_short") or cb.get("sample", ""))[:200]
+    if res.get("multi_gpu"):
+        m = res["multi_gpu"]
+        line["multi_gpu"] = {k: m.get(k) for k in ("headline_exchange", "layout", "behind_c_abi", "overlapped", "second_pass", "step_ms", "render_ms_per_step",
+                                                   "exchange_alone_ms_per_step", "hidden_ms_per_step", "bytes_sent_per_rank_per_step",
+                                                   "predicted_exchange_ms_at_xgmi_peak", "bgr8", "predicted", "fallback") if m.get(k) is not None}
+    line["details"] = "bench_details.json (+ stderr): every note and configs[] at full precision"
+    out = json.dumps(compact(line, 5), separators=(",", ":"))
+    if len(out) >= LINE_LIMIT:  # never let extras cost the parse: drop the nested tables first, the flat scalars stay
+        for k in ("multi_gpu_emulated", "per_config"):
+            line["roofline"].pop(k, None)
+            out = json.dumps(compact(line, 5), separators=(",", ":"))
+            if len(out) < LINE_LIMIT:
+                break
+    sys.stdout.flush()
+    print(out, flush=True)
+
+
 def multi_gpu_budget(args, world, wl_name):
     """HBM the N > 1 loop allocates per rank, checked BEFORE anything is allocated (the in-place exchange keeps 2 gathered
     buffers of world x shard each; the headline's 8-bit ones and the float planes' are not alive together)"""
@@ -609,9 +773,9 @@ def main():
                     help="raster: post-MVP triangle streams resident in HBM (BASELINE's hot path); "
                          "draw: meshes + per-frame matrices resident, the vertex stage (k_vertex) is timed too")
     ap.add_argument("--exchange", choices=["bgr8", "planes", "both"], default="both",
-                    help="N>1 only. bgr8: resolve to 8-bit on the device and all-gather display()'s image, the reference's final "
-                         "m_frameBuffer (3 B/px) — the headline; planes: all-gather the 4 float planes (16 B/px: z + m_channels); "
-                         "both: the headline exchanges bgr8 and a second, shorter pass times planes (multi_gpu.planes)")
+                    help="N>1 only. planes: all-gather the 4 float planes (16 B/px: z + m_channels) — the headline; bgr8: resolve to "
+                         "8-bit on the device and all-gather display()'s image (3 B/px); both: the headline exchanges the planes and "
+                         "a second, shorter pass times bgr8 (multi_gpu.bgr8)")
     ap.add_argument("--exchange-layout", choices=["shards", "rows"], default="shards",
                     help="N>1 only. shards: render into the rank's slot of the gathered buffer, ONE in-place all-gather, no second "
                          "pass (frames stay in rank-major shard order); rows: all-gather + a HIP de-interleave pass (row-major frames)")
@@ -679,26 +843,27 @@ def main():
     if not multi_path:
         dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes)
     else:
-        head_x = "planes" if args.exchange == "planes" else "bgr8"
+        head_x = "bgr8" if args.exchange == "bgr8" else "planes"
         dt, kt, per_step, multi = time_multi_gpu(case, comm, dist, args.steps, args.warmup, fence, head_x,
                                                  args.no_overlap, args.exchange_layout, rank)
         multi.pop("last_full")
         multi["headline_exchange"] = head_x
-        multi["why"] = ("bgr8 = display()'s m_frameBuffer after convertTo(CV_8UC3) (src/Render.cpp:61-62 of the reference): the final "
-                        "framebuffer; planes = z + the three float m_channels (what draw() leaves)")
+        multi["why"] = ("planes = z + the three float m_channels, what draw() leaves and what north_star's parity is stated on (z bit-exact): "
+                        "the headline at every N; bgr8 = display()'s m_frameBuffer after convertTo(CV_8UC3) (src/Render.cpp:61-62 of the "
+                        "reference), 3 B/px, reported beside it and never as `value` unless --exchange bgr8 is asked for")
         multi["budget"] = budget
         multi["predicted"] = {"bgr8": predicted_exchange(budget["shard_bytes_bgr8"], case.n_frames),
                               "planes": predicted_exchange(budget["shard_bytes_planes"], case.n_frames),
                               "source": "DESIGN.md §6: shard bytes / 153 GB/s per xGMI link; render (≈ the N = 1 step) hidden under it"}
-        if args.exchange == "both":  # the float planes beside the headline: fewer steps (≈ 5x the bytes per step)
+        if args.exchange == "both":  # display()'s 8-bit image beside the headline
             torch.cuda.empty_cache()
-            k2 = max(3, args.steps // 4)
-            dt2, kt2, _, m2 = time_multi_gpu(case, comm, dist, k2, min(args.warmup, 2), fence, "planes", args.no_overlap,
+            k2 = max(3, args.steps // 2)
+            dt2, kt2, _, m2 = time_multi_gpu(case, comm, dist, k2, min(args.warmup, 2), fence, "bgr8", args.no_overlap,
                                              args.exchange_layout, rank)
             m2.pop("last_full")
-            multi["planes"] = {"frames_per_sec": case.n_frames * k2 / dt2, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
-                               "render_ms_per_step": m2["render_ms_per_step"], "exchange_alone_ms_per_step": m2["exchange_alone_ms_per_step"],
-                               "hidden_ms_per_step": m2["hidden_ms_per_step"], "bytes_sent_per_rank_per_step": m2["bytes_sent_per_rank_per_step"]}
+            multi["bgr8"] = {"frames_per_sec": case.n_frames * k2 / dt2, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+                             "render_ms_per_step": m2["render_ms_per_step"], "exchange_alone_ms_per_step": m2["exchange_alone_ms_per_step"],
+                             "hidden_ms_per_step": m2["hidden_ms_per_step"], "bytes_sent_per_rank_per_step": m2["bytes_sent_per_rank_per_step"]}
         if comm_note:
             multi["fallback"] = comm_note
 
@@ -722,10 +887,14 @@ def main():
                              "start-to-end; one_stream = the batch in one piece on one stream, measured after the timed region "
                              "(where the per-kernel split comes from). algorithmic bytes = "
                              "16*W*rows + 96*N_tri + 24*N_lights + min(3*texW*texH, 3*textured_px) per frame"})
+        udt = kt.get("unprimed_dt")
         res = {
             "metric": "frames_per_sec", "value": rec["frames_per_sec"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "priming_steps": max(0, PRIME_TO - args.warmup),
-            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "priming_steps": kt.get("priming_steps", max(0, PRIME_TO - args.warmup)),
+            "ms_per_step": rec["ms_per_step"],
+            "value_unprimed": (case.n_frames * args.steps / udt) if udt else None,
+            "ms_per_step_unprimed": (udt / args.steps * 1e3) if udt else None,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": fs.width, "height": fs.height,
                        "frames_per_step": case.n_frames, "frames_per_step_per_gpu": args.frames,
@@ -744,34 +913,50 @@ def main():
     case.close()
 
     # ---- N = 1: the other GPU configs of BASELINE.json + configs[1] at scope draw, each outside the headline's timed region
+    extras = []
     if not multi_path and not args.no_extras:
-        extras = []
-        todo = [(w, f, s, "raster", args.lanes) for (w, f, s) in EXTRA_CASES if w != args.workload]
-        todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster", args.lanes))
+        todo = [(w, f, s, "raster", args.lanes, 0) for (w, f, s) in EXTRA_CASES if w != args.workload]
+        todo.append((args.workload, args.frames, max(5, args.steps // 2), "draw" if args.scope == "raster" else "raster", args.lanes, 0))
         # the headline workload once more the other way (one frameset on one stream / two lanes on two streams)
-        todo.append((args.workload, args.frames, args.steps, args.scope, 2 if args.lanes == 1 else 1))
+        todo.append((args.workload, args.frames, args.steps, args.scope, 2 if args.lanes == 1 else 1, 0))
+        # the tolerance mode (SRZ_OPT_APPROX_SHADE: the reference's own arithmetic class) on the configs it is for
+        todo += [(w, f, s, "raster", args.lanes, 1) for (w, f, s) in APPROX_CASES]
         per_config = {}
-        for (w, f, s, scope, n_lanes) in todo:
+        for (w, f, s, scope, n_lanes, approx) in todo:
             try:
+                if approx:
+                    ctx.set_option(abi.OPT_APPROX_SHADE, 1)
                 c = Case(ctx, torch, w, f, scope, 1)
                 d, k, ps = time_single_gpu(c, s, 15 if w == args.workload else 8, fence, n_lanes)
                 extras.append(case_record(c, s, d, k, ps, c.stats["fragments"], c.stats["visible"]))
+                extras[-1]["approx_shade"] = bool(approx)
                 c.close()
             except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
-                extras.append({"workload": w, "scope": scope, "error": str(e)})
-            if w in PER_CONFIG and scope == "raster":
+                extras.append({"workload": w, "scope": scope, "error": str(e)[:200]})
+            finally:
+                if approx:
+                    ctx.set_option(abi.OPT_APPROX_SHADE, 0)
+            if approx:
+                per_config[w + ":approx"] = per_config_summary(extras[-1])
+            elif w in PER_CONFIG and scope == "raster":
                 per_config[w] = per_config_summary(extras[-1])
             elif w == args.workload and scope == "draw":
                 per_config[w + ":draw"] = per_config_summary(extras[-1])
+            elif w == args.workload and scope == args.scope:
+                per_config[w + f":lanes{n_lanes}"] = per_config_summary(extras[-1])
         if loop_rec is not None:
             extras.append(loop_rec)
             per_config["readme_spot_crate_1024:readme_loop"] = per_config_summary(loop_rec)
-        res["configs"] = extras
         res["roofline"]["per_config"] = per_config
+        # the render-side term of the N-GPU job, measured on this one GPU
+        try:
+            res["roofline"]["multi_gpu_emulated"] = emulate_shards(srz, torch, local_rank, fence, args)
+        except Exception as e:  # noqa: BLE001
+            res["roofline"]["multi_gpu_emulated"] = {"error": str(e)[:200]}
     if not multi_path and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_budget_s)
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res, extras)
     if comm is not None:
         comm.close()
     if multi_path:

@@ -39,8 +39,9 @@ extern "C" {
  *      srz_comm_*, srz_frameset_allgather / _deinterleave / _exchange_bytes, srz_kernel_time_samples
  *   4  srz_frameset_allgather_inplace, srz_frameset_gathered_row_offset, srz_frameset_read_gathered_frame
  *   5  srz_set_option, srz_verify_fastpow; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
+ *   6  SRZ_OPT_APPROX_SHADE (the tolerance mode of the shaders); srz_frameset_resolve8 / _deinterleave / the bgr8 exchange take any width
  */
-#define SRZ_ABI_VERSION 5
+#define SRZ_ABI_VERSION 6
 
 /* error codes */
 #define SRZ_OK 0
@@ -167,6 +168,15 @@ const char *srz_last_error(const srz_ctx *ctx); /* ctx may be NULL: last error o
  *                      render has grown the pool).  Default 0, or 1 when the environment variable SRZ_POOL_LAZY is set — read
  *                      ONCE, in srz_create. */
 #define SRZ_OPT_POOL_LAZY 1
+/*   SRZ_OPT_APPROX_SHADE  1 = TOLERANCE MODE of the fragment shaders (default 0 = exact: bit-identical to the CPU oracle).  The
+ *                      reference's x86 path shades with approximate instructions — _mm256_rcp_ps (include/shader/Shader.hpp:131,
+ *                      src/Tools.cpp:19, include/loader/TextureLoader.hpp:99, src/Rasterizer.cpp:111) and SVML _mm256_pow_ps
+ *                      (include/shader/Shader.hpp:195); this switch gives the colour arithmetic the same class on gfx950 (v_rcp_f32 /
+ *                      v_rsq_f32 / v_sqrt_f32 at 1 ulp, x^p = exp2(p log2 x)).  Depth, coverage and ownership stay bit-exact (the
+ *                      rasteriser does not change); colours: 8-wide ("V") columns within 0.5 of the exact value on the 0..255 scale,
+ *                      scalar-tail ("S") columns equal except where the value in front of the floor lies within 1e-3 of an integer
+ *                      (tests/test_gpu_approx.py).  Frames with 1..4 lights and no BUMP / DISPLACEMENT batch take it; others stay exact. */
+#define SRZ_OPT_APPROX_SHADE 2
 int srz_set_option(srz_ctx *ctx, int option, int value);
 
 /* Multi-GPU: this ctx owns the 32-row bands b with b % world == rank (local band b / world).
@@ -224,7 +234,7 @@ int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_
                         uint32_t flags, void *stream);
 /* display()'s resolve on the device (cv::merge + convertTo(CV_8UC3), src/Render.cpp:61-62): the three colour planes of
  * a rendered buffer (layout of srz_frameset_render) → interleaved 8-bit [frame][local_rows][width][3], round half to even,
- * saturate.  Asynchronous on `stream`.  width must be a multiple of 4. */
+ * saturate.  Asynchronous on `stream`.  Any width (sizes whose plane is not a multiple of 4 pixels take a one-pixel-per-thread kernel). */
 int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_planes, void *d_bgr8, size_t bgr8_bytes,
                           void *stream);
 /* Re-upload the per-frame data of a sceneset (matrices, eye, lights, shader constants, flags, shader/texture per draw)

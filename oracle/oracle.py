@@ -162,6 +162,12 @@ def draw_frames_omp(frames, n_total, threads=0, fast=False):
     return rc, n.value
 
 
+def debug_s(mode):
+    """test probe: 0 = the reference's result; 1 = scalar-tail pixels keep the value in front of the truncation; 2 = scalar-tail
+    pixels are written as -1 (a class marker).  Only the -O2 checker build; reset it to 0 when done."""
+    lib().orc_debug_s(int(mode))
+
+
 def resolve8(planes):
     _, c0, c1, c2 = planes
     h, w = c0.shape

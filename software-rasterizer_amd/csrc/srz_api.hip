@@ -60,6 +60,7 @@ struct srz_ctx {
   int env_sub_batch = 0;
   bool env_no_packed = false; // SRZ_NO_PACKED (tests): see srz_frameset::no_packed
   bool env_no_turns = false;  // SRZ_NO_TURNS (A/B): renders on different streams do not wait for each other's k_raster
+  bool opt_approx_shade = false; // SRZ_OPT_APPROX_SHADE (srz_set_option): framesets created from now on shade in the tolerance mode
   bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
@@ -114,6 +115,7 @@ struct srz_frameset {
   bool any_generic = true;  // some frame needs the generic build
   uint32_t *d_vis = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr; // d_vis: the per-tile pixel lists (srz_device.h)
   uint4 *d_worklist = nullptr;
+  bool approx_shade = false; // SRZ_OPT_APPROX_SHADE at creation: frames of 1..4 lights without BUMP / DISPLACEMENT batches are shaded by the ApproxMath builds
   bool no_packed = false; // SRZ_NO_PACKED (tests): no frame is FD_PACKED — 32-bit owner ids by triangle index, no staged triangles
   uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
   uint2 *d_band_ent = nullptr;     // and entries [group][ENT_PER_GROUP]
@@ -186,12 +188,16 @@ void classify_frames(srz_frameset *fs) {
       bumpy = bumpy || sh == SRZ_SHADER_BUMP || sh == SRZ_SHADER_DISPLACEMENT;
     }
     const bool fracpow = d.p > 0.0f && d.p <= 4096.0f && d.p != std::trunc(d.p); // (pow_fast's domain)
-    const bool fast = d.n_lights >= 1u && d.n_lights <= 4u && (intpow || (fracpow && !bumpy));
+    // the tolerance mode (SRZ_OPT_APPROX_SHADE): its builds take any finite exponent >= 0 (exp2(p log2 x)) through the plain kinds'
+    // work lists; frames they do not cover keep the exact generic build
+    const bool approx = fs->approx_shade && d.n_lights >= 1u && d.n_lights <= 4u && !bumpy && d.p >= 0.0f && std::isfinite(d.p);
+    const bool fast = approx || (!fs->approx_shade && d.n_lights >= 1u && d.n_lights <= 4u && (intpow || (fracpow && !bumpy)));
+    const bool plain = approx || intpow;
     d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | FD_PACKED | (7u << FD_NL_SHIFT))) |
-              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (intpow ? 0u : FD_GENPOW)) : 0u) |
+              (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (plain ? 0u : FD_GENPOW)) : 0u) |
               ((d.n_tris < PACK_IDX_MASK && d.n_batches <= PACK_MAX_BATCHES && !fs->no_packed) ? FD_PACKED : 0u);
     if (fast)
-      fs->fast_mask |= 1u << (d.n_lights + (bumpy ? 8u : 0u) + (intpow ? 0u : 16u));
+      fs->fast_mask |= 1u << (d.n_lights + (bumpy ? 8u : 0u) + (plain ? 0u : 16u));
     else
       fs->any_generic = true;
   }
@@ -495,7 +501,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       ctx->raster_last_stream = s, ctx->raster_valid = true;
     }
     if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t2, s));
-    launch_shade(v, tiles, stats, fs->fast_mask, fs->any_generic, s);
+    launch_shade(v, tiles, stats, fs->fast_mask, fs->any_generic, fs->approx_shade, s);
     if (side) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[ev], 0));
     else if (!raster_four_waves(v))
       if (int rc = copy_demand(s)) return rc;
@@ -612,8 +618,12 @@ const char *srz_last_error(const srz_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 int srz_set_option(srz_ctx *ctx, int option, int value) {
   if (!ctx) return SRZ_E_INVALID;
-  if (option != SRZ_OPT_POOL_LAZY) return fail(ctx, SRZ_E_INVALID, "srz_set_option: unknown option " + std::to_string(option));
-  ctx->opt_pool_lazy = value != 0;
+  if (option == SRZ_OPT_POOL_LAZY)
+    ctx->opt_pool_lazy = value != 0;
+  else if (option == SRZ_OPT_APPROX_SHADE)
+    ctx->opt_approx_shade = value != 0;
+  else
+    return fail(ctx, SRZ_E_INVALID, "srz_set_option: unknown option " + std::to_string(option));
   return SRZ_OK;
 }
 
@@ -713,6 +723,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   }
   fs->total_tris = tri_off, fs->total_lights = light_off, fs->total_groups = group_off;
   fs->no_packed = ctx->env_no_packed;
+  fs->approx_shade = ctx->opt_approx_shade;
   fs->pool_sized = ctx->opt_pool_lazy; // (SRZ_OPT_POOL_LAZY: no first-render sizing — the pool only follows the previous renders' demand)
   classify_frames(fs);
 
@@ -744,7 +755,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   if (e == hipSuccess) e = (expr)
   FS_TRY(dev_alloc((void **)&fs->d_frames, sizeof(FrameDesc) * n_frames));
   FS_TRY(dev_alloc((void **)&fs->d_tris, sizeof(srz_tri) * tri_off));
-  if (!fs->tris_aos) FS_TRY(dev_alloc((void **)&fs->d_tri_pos, sizeof(float) * TRI_POS_F * tri_off + 16)); // (+16: the last triangle's 9 floats are read as 4 + 4 + 1)
+  if (!fs->tris_aos) FS_TRY(dev_alloc((void **)&fs->d_tri_pos, sizeof(float) * TRI_POS_F * tri_off + 16)); // (+16: slack behind the last triangle's 9 floats, which are read as three 12-byte pieces)
   FS_TRY(dev_alloc((void **)&fs->d_bbox, sizeof(BBox) * tri_off));
   FS_TRY(dev_alloc((void **)&fs->d_chunk_rows, sizeof(uint32_t) * (tri_off / 64 + (size_t)n_frames + 1)));
   FS_TRY(dev_alloc((void **)&fs->d_band_desc, sizeof(uint32_t) * group_off * fs->n_local_bands));
@@ -1039,18 +1050,6 @@ int srz_target_read_bgr8(srz_ctx *ctx, srz_target *t, uint8_t *bgr8) {
   int rc = target_materialize_clear(ctx, t);
   if (rc) return rc;
   const size_t plane = (size_t)t->width * t->height;
-  if (t->width & 3) { // odd widths: resolve on the host from the planes (rare; keeps the kernel's 4-pixel contract)
-    std::vector<float> c(plane * 3);
-    HIP_TRY(ctx, hipMemcpyAsync(c.data(), t->d_planes + plane, plane * 12, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < plane; ++i)
-      for (int k = 0; k < 3; ++k) {
-        float v = c[k * plane + i];
-        float r = (v == v) ? std::nearbyintf(v) : 0.0f;
-        bgr8[i * 3 + k] = (uint8_t)(r <= 0.0f ? 0 : (r >= 255.0f ? 255 : (int)r));
-      }
-    return SRZ_OK;
-  }
   launch_resolve8(t->d_planes, t->d_bgr8, 1, (uint32_t)t->height, (uint32_t)t->width, 4ull * plane, ctx->stream);
   HIP_TRY(ctx, hipMemcpyAsync(bgr8, t->d_bgr8, plane * 3, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1089,9 +1088,8 @@ int srz_frameset_render(srz_ctx *ctx, srz_frameset *fs, void *d_out, size_t out_
 int srz_frameset_resolve8(srz_ctx *ctx, const srz_frameset *fs, const void *d_planes, void *d_bgr8, size_t bgr8_bytes, void *stream) {
   if (!ctx) return SRZ_E_INVALID;
   if (!fs || !d_planes || !d_bgr8) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: null argument");
-  if (fs->width & 3) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: width must be a multiple of 4");
   if (bgr8_bytes < (size_t)fs->n_frames * fs->local_rows * (size_t)fs->width * 3) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: output too small");
-  if (((uintptr_t)d_planes & 15u) || ((uintptr_t)d_bgr8 & 3u)) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: misaligned buffer");
+  if ((uintptr_t)d_planes & 3u) return fail(ctx, SRZ_E_INVALID, "srz_frameset_resolve8: misaligned planes");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = pick_stream(ctx, stream);
   launch_resolve8((const float *)d_planes, (uint8_t *)d_bgr8, (uint32_t)fs->n_frames, fs->local_rows, (uint32_t)fs->width,
@@ -1324,8 +1322,8 @@ int srz_frameset_deinterleave(srz_ctx *ctx, const srz_frameset *fs, const void *
     return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: bad arguments");
   if (fs->shard_world == 1) return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: the frameset is not sharded");
   const uint32_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (uint32_t)fs->width * 3u : (uint32_t)fs->width * 4u;
-  if (row_bytes & 3u) return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: rows must be a multiple of 4 bytes");
-  if (((uintptr_t)d_gathered | (uintptr_t)d_full) & 3u) return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: misaligned buffer");
+  if (what == SRZ_EXCHANGE_PLANES && (((uintptr_t)d_gathered | (uintptr_t)d_full) & 3u))
+    return fail(ctx, SRZ_E_INVALID, "srz_frameset_deinterleave: misaligned buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = pick_stream(ctx, stream);
   launch_deinterleave(d_gathered, d_full, (uint32_t)fs->shard_world, (uint32_t)fs->n_frames * (what == SRZ_EXCHANGE_BGR8 ? 1u : 4u),
@@ -1461,6 +1459,7 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
   int rc = SRZ_OK;
   bool reuse = ctx->draw_fs && sig == ctx->draw_sig;
   if (reuse) {
+    ctx->draw_fs->approx_shade = ctx->opt_approx_shade; // (the ctx's own one-frame set follows the option call by call)
     rc = frame ? refresh_plain_frame(ctx, ctx->draw_fs, *frame, s) : srz_sceneset_update(ctx, ctx->draw_fs, scene, 1);
     if (rc != SRZ_OK && !frame) reuse = false, rc = SRZ_OK; // (a scene whose mesh bindings changed: rebuild)
     if (rc != SRZ_OK) return rc;

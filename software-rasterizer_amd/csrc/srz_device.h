@@ -28,7 +28,7 @@ constexpr uint32_t FD_PACKED = 0x4000u;                  // fewer than 2^22 - 1 
                                                          // triangle index | batch << 22 (k_shade stages the tile's triangles without
                                                          // a gather of their batch ids), and the depth keys' tie-breaks carry list positions
 constexpr uint32_t PACK_IDX_BITS = 22, PACK_IDX_MASK = (1u << PACK_IDX_BITS) - 1u, PACK_MAX_BATCHES = 1024;
-constexpr uint32_t FD_GENPOW = 0x2000u;                  // the exponent is not an integer 0..256: FAST builds whose power is pow_cr (ocml pow in binary64)
+constexpr uint32_t FD_GENPOW = 0x2000u;                  // a non-integer exponent in (0, 4096]: FAST builds whose power is pow_fast (exp2(p log2 x) in binary64 with a rounding-safety flag)
 constexpr uint32_t SHADE_KIND_GENERIC = 12;              // k_shade builds: kinds 0..3 = FAST for 1..4 lights, 4..7 = the same + BUMPY,
                                                          // 8..11 = FAST for 1..4 lights with any exponent (GENPOW), 12 = generic
 constexpr uint32_t N_WORK_LISTS = 8 * (SHADE_KIND_GENERIC + 1);
@@ -172,7 +172,7 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
 void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);
 bool raster_four_waves(const RenderArgs &a); // the latency build of k_raster serves this job (it also reports the pool's demand)
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
-void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, hipStream_t s);
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, bool approx, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s);
 void launch_deinterleave(const void *gathered, void *full, uint32_t world, uint32_t n_fp, uint32_t bands_per_rank, uint32_t row_bytes,

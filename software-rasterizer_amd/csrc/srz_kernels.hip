@@ -120,6 +120,12 @@ __device__ __forceinline__ bool div_num_ok(float a) { // (int |, &: no short-cir
   return ((int)(f2u_(a) == 0u) | (int)((((f2u_(a) >> 23) & 0xffu) - 67u) <= 120u)) != 0;
 }
 __device__ __forceinline__ bool div_den_ok(float b) { return ((f2u_(b) >> 23) - 87u) <= 80u; } // 2^-40 <= b <= 2^40, b > 0
+// sqrt(a^2 + b^2) as the scalar Blinn-Phong computes its attenuation distance (src/Shader.cpp:516-523: std::pow(x, 2) and std::sqrt
+// in binary64, rounded once)
+__device__ __forceinline__ float len2d_f64(float a, float b) {
+  const double dx = (double)a, dy = (double)b;
+  return (float)__builtin_sqrt(dx * dx + dy * dy);
+}
 struct BranchMath {
   __device__ __forceinline__ float rcp(float x) { return rcp_rn(x); }
   __device__ __forceinline__ float sqrt(float x) { return sqrt_rn(x); }
@@ -133,6 +139,8 @@ struct IeeeMath {
   __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
   __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
+  __device__ __forceinline__ float len2d(float a, float b) { return len2d_f64(a, b); }
+  __device__ __forceinline__ float div(float a, float b) { return a / b; }
 };
 struct FastMath {
   bool bad = false; // (the rare checks: division operands, pow_fast's rounding flag)
@@ -163,6 +171,27 @@ struct FastMath {
     track(f2u_(d));
     return rcp_core(sqrt_core(d));
   }
+  __device__ __forceinline__ float len2d(float a, float b) { return len2d_f64(a, b); }
+  __device__ __forceinline__ float div(float a, float b) { return a / b; }
+};
+// ApproxMath — the TOLERANCE mode (SRZ_OPT_APPROX_SHADE, opt-in; never the default): the arithmetic CLASS of the reference's own
+// x86 path, which shades with approximate instructions — _mm256_rcp_ps (include/shader/Shader.hpp:131, src/Tools.cpp:19,
+// include/loader/TextureLoader.hpp:99, src/Rasterizer.cpp:111: 12 bits) and SVML _mm256_pow_ps (include/shader/Shader.hpp:195) —
+// on the hardware's own: bare v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp), x^p = v_exp_f32(p * v_log_f32(x)), texel * (1/255), the
+// binary64 pieces of the scalar path (the attenuation distance, std::pow) in binary32.  Only k_shade's colour arithmetic takes it:
+// k_raster stays exact, so z, coverage and ownership are bit-identical to the oracle in this mode too.  Nothing can go out of a
+// "fast range" here — no operand tracking, no re-shade.  tests/test_gpu_approx.py states the tolerance.
+struct ApproxMath {
+  __device__ __forceinline__ float div255(float a) { return a * (1.0f / 255.0f); }
+  __device__ __forceinline__ void div3(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2) {
+    const float y = __builtin_amdgcn_rcpf(b);
+    q0 = a0 * y, q1 = a1 * y, q2 = a2 * y;
+  }
+  __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  __device__ __forceinline__ float rsqrt2(float d) { return __builtin_amdgcn_rsqf(d); }
+  __device__ __forceinline__ float len2d(float a, float b) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(a, a, b * b)); }
+  __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -190,6 +219,13 @@ __device__ __forceinline__ void v_normalized(FastMath &m, float &x, float &y, fl
   const float d = fmaf_(x, x, fmaf_(y, y, z * z));
   m.track(f2u_(d));
   const float inv = rcp_core(sqrt_core(d));
+  x = x * inv, y = y * inv, z = z * inv;
+}
+
+// ApproxMath: one v_rsq_f32; the zero vector stays the zero vector as in NormalSIMD::normalized
+__device__ __forceinline__ void v_normalized(ApproxMath &m, float &x, float &y, float &z) {
+  const float d = fmaf_(x, x, fmaf_(y, y, z * z));
+  const float inv = d > 0.0f ? __builtin_amdgcn_rsqf(d) : 0.0f;
   x = x * inv, y = y * inv, z = z * inv;
 }
 
@@ -296,8 +332,16 @@ __device__ __forceinline__ float pow_fast(float x, float p, bool &amb) {
 //   NL < 0  a non-integer exponent in (0, 4096] (Shader::p is a mutable static in the reference: any value is legal): pow_fast,
 //           whose ambiguous cases the FastMath pass's `bad` flag takes to the generic build
 //   NL = 0  the generic build, every other exponent: pow_cr
+// x^p in the tolerance mode: exp2(p * log2 x) on the transcendental unit (x >= 0 here: a clamped cosine; x = 0 → log2 = -inf →
+// +0 for p > 0).  p = 0 (wave-uniform) is 1 whatever x, as pow() has it
+__device__ __forceinline__ float pow_approx(float x, float p) {
+  if (p == 0.0f) return 1.0f;
+  return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));
+}
 template <int NL, class M> __device__ __forceinline__ float pow_frame(M &m, float x, float p) {
-  if constexpr (NL > 0) {
+  if constexpr (std::is_same<M, ApproxMath>::value) {
+    return pow_approx(x, p);
+  } else if constexpr (NL > 0) {
     return p == 150.0f ? pow150_cr(x) : pow_int_cr(x, p); // (wave-uniform branch: p is a per-frame scalar)
   } else if constexpr (NL < 0 && std::is_same<M, FastMath>::value) {
     return pow_fast(x, p, m.bad); // (the host sends only frames with a non-integer exponent in (0, 4096] to these builds)
@@ -334,6 +378,7 @@ __device__ __forceinline__ bool cover_v(const TriXY &t, float fx, float fy, floa
   return alpha > 0.0f && alpha < 1.0f && beta > 0.0f && beta < 1.0f && gamma > 0.0f && gamma < 1.0f;
 }
 // "S" semantics: insideTriangle + barycentric(scalar) + z (src/Rasterizer.cpp:11-70,473)
+template <class M = IeeeMath>
 __device__ __forceinline__ bool cover_s(const TriXY &t, float fx, float fy, float &alpha, float &beta, float &gamma,
                                         float &z) {
   float ABx = t.bx - t.ax, ABy = t.by - t.ay, BCx = t.cx - t.bx, BCy = t.cy - t.by, CAx = t.ax - t.cx, CAy = t.ay - t.cy;
@@ -342,7 +387,13 @@ __device__ __forceinline__ bool cover_s(const TriXY &t, float fx, float fy, floa
   bool inside = (e0 > 0 && e1 > 0 && e2 > 0) || (e0 < 0 && e1 < 0 && e2 < 0);
   float PAx = t.ax - fx, PAy = t.ay - fy, PBx = t.bx - fx, PBy = t.by - fy, PCx = t.cx - fx, PCy = t.cy - fy;
   float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
-  alpha = aPBC / t.s_area, beta = aPCA / t.s_area, gamma = 1.0f - alpha - beta;
+  if constexpr (std::is_same<M, ApproxMath>::value) { // (k_shade's tolerance mode only: one reciprocal for both)
+    const float y = __builtin_amdgcn_rcpf(t.s_area);
+    alpha = aPBC * y, beta = aPCA * y;
+  } else {
+    alpha = aPBC / t.s_area, beta = aPCA / t.s_area;
+  }
+  gamma = 1.0f - alpha - beta;
   z = alpha * t.z0 + beta * t.z1 + gamma * t.z2;
   return inside;
 }
@@ -1021,8 +1072,7 @@ __device__ __forceinline__ void s_blinn_phong(M &m, const FrameK &K, float px, f
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
   normalize3(m, nx, ny, nz);
   float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
-  double dx = (double)(Lx - px), dy = (double)(Ly - py);
-  float dsq = (float)__builtin_sqrt(dx * dx + dy * dy);
+  float dsq = m.len2d(ldx, ldy); // (binary64 in the reference: std::pow(x, 2), std::sqrt)
   float d0, d1, d2;
   m.div3(I0, I1, I2, dsq, d0, d1, d2);
   float nlx = ldx, nly = ldy, nlz = ldz;
@@ -1044,8 +1094,7 @@ __device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float
   const float Lx = L->pos[0], Ly = L->pos[1], Lz = L->pos[2], I0 = L->intensity[0], I1 = L->intensity[1], I2 = L->intensity[2];
   normalize3(m, nx, ny, nz);
   float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
-  double dx = (double)(Lx - px), dy = (double)(Ly - py);
-  float dsq = (float)__builtin_sqrt(dx * dx + dy * dy);
+  float dsq = m.len2d(ldx, ldy); // (binary64 in the reference: std::pow(x, 2), std::sqrt)
   m.div3(I0, I1, I2, dsq, t.d0, t.d1, t.d2);
   float nlx = ldx, nly = ldy, nlz = ldz;
   normalize3(m, nlx, nly, nlz);
@@ -1248,7 +1297,12 @@ template <class M, int SH = -1, int NL = 0>
 __device__ __forceinline__ void shade_pixel_v(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f_in, const f32x4 *late, int x,
                                               int y, float &r0, float &r1, float &r2) {
   TriAttr a;
-  TriFetch f = f_in; // (a local copy: what the staged reads below define must not outlive this call — the caller's loops would carry it)
+  TriFetch f; // (a local copy: what the staged reads below define must not outlive this call — the caller's loops would carry it)
+  if constexpr (std::is_same<M, ApproxMath>::value) { // (a staged triangle: nothing of f_in but the batch id is defined — copying the
+    if (late == nullptr) f = f_in;                    // struct left a dead 4-byte scratch store per chunk in the tolerance builds)
+  } else {
+    f = f_in;
+  }
   early_fetch(f, late);
   unpack_pos(m, f, a);
   const float fx = (float)x, fy = (float)y;
@@ -1269,12 +1323,17 @@ template <class M, int SH = -1, int NL = 0>
 __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const ShadeDesc &sd, const TriFetch &f_in, const f32x4 *late, int x,
                                               int y, float &r0, float &r1, float &r2) {
   TriAttr a;
-  TriFetch f = f_in; // (a local copy: what the staged reads below define must not outlive this call — the caller's loops would carry it)
+  TriFetch f; // (a local copy: what the staged reads below define must not outlive this call — the caller's loops would carry it)
+  if constexpr (std::is_same<M, ApproxMath>::value) { // (a staged triangle: nothing of f_in but the batch id is defined — copying the
+    if (late == nullptr) f = f_in;                    // struct left a dead 4-byte scratch store per chunk in the tolerance builds)
+  } else {
+    f = f_in;
+  }
   early_fetch(f, late);
   unpack_pos(m, f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
-  cover_s(a.t, fx, fy, alpha, beta, gamma, zz);
+  cover_s<std::conditional_t<std::is_same<M, ApproxMath>::value, ApproxMath, IeeeMath>>(a.t, fx, fy, alpha, beta, gamma, zz);
   late_fetch(f, late, gamma);
   unpack_attr(f, a);
   float nx = alpha * a.n0x + beta * a.n1x + gamma * a.n2x;
@@ -2051,6 +2110,8 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 #define SRZ_STAGE_TRIS 96 // triangles of a tile's list k_shade stages in LDS (12 KB colours + 4 KB lists + 9 KB triangles: 6 workgroups per CU)
 #endif
 constexpr uint32_t STAGE_TRIS = SRZ_STAGE_TRIS, STAGE_SD = 16;
+// (s_tri doubles as the {pixel, index} pair list of tiles whose ids are triangle indices: 2 dwords per pixel of the tile)
+static_assert(SRZ_STAGE_TRIS * 6 * 16 >= 2 * 32 * 32 * 4, "SRZ_STAGE_TRIS: s_tri must hold a tile's 1024 {pixel, index} pairs (>= 86 triangles)");
 #ifndef SRZ_GENPOW_MINW
 #define SRZ_GENPOW_MINW 5 // (the builds with pow_fast: 81 VGPRs for two lights; held to 80 they spill 20 bytes into the chunk loops: -3 %)
 #endif
@@ -2064,14 +2125,18 @@ constexpr uint32_t STAGE_TRIS = SRZ_STAGE_TRIS, STAGE_SD = 16;
 //            optimistic FastMath only — a tile where an operand left the fast range is handed back through redo_list.
 //   generic  every other frame with per-pixel generality (any shader, any light count, any exponent), FastMath first and
 //            the IEEE expansions for a tile that needs them; then the tiles the FAST build handed back, IEEE at once.
-//   FASTNL < 0: the FAST build for -FASTNL lights and ANY exponent (pow_cr: ocml's binary64 pow for a non-integer one) — frames that
+//   FASTNL < 0: the FAST build for -FASTNL lights and a non-integer exponent in (0, 4096] (pow_fast; its ambiguous roundings go to the generic build) — frames that
 //            differ from the common case only in Shader::p keep the per-chunk variants, the unrolled lights and the hoisted texel
-template <bool STATS, int FASTNL, bool BUMPY = false>
+//   APPROX   (SRZ_OPT_APPROX_SHADE, one build per light count 1..4): the FAST walk with the ApproxMath policy — the tolerance mode.
+//            Any exponent (x^p is exp2(p log2 x) there), never a re-shade; frames it does not cover (0 or > 4 lights, BUMP /
+//            DISPLACEMENT batches) keep the exact builds.
+template <bool STATS, int FASTNL, bool BUMPY = false, bool APPROX = false>
 __global__ __launch_bounds__(256, (FASTNL > 0 && FASTNL <= 2 && !BUMPY) ? SRZ_FAST_MINW : (FASTNL < 0 && FASTNL >= -2) ? SRZ_GENPOW_MINW
                                   : ((FASTNL == 3 || FASTNL == -3) && !BUMPY) ? 5 : SRZ_SHADE_MINW)
 void k_shade(RenderArgs a) {
   constexpr bool FAST = FASTNL != 0, GENPOW = FASTNL < 0;
   static_assert(FAST || !BUMPY, "BUMPY is a property of the FAST builds");
+  static_assert(!APPROX || (FASTNL > 0 && !BUMPY && !STATS), "the tolerance mode has FAST builds for 1..4 lights only");
   static_assert(!(GENPOW && BUMPY), "frames with BUMP / DISPLACEMENT batches and a non-integer exponent take the generic build");
   __shared__ __attribute__((aligned(16))) float s_c[3][TILE * TILE];
   // the tile's owned pixels compacted by class: V entries [0, nV), S entries [nV, nV + nS), row-major each; an entry = pixel |
@@ -2217,9 +2282,13 @@ void k_shade(RenderArgs a) {
         }
       }
     }
-    // raw barrier: only the LDS stores above must be visible (lgkmcnt); the DMA pieces stay in flight across it
+    // raw barrier: only the LDS stores above must be visible (lgkmcnt); the DMA pieces stay in flight across it.  s_barrier is
+    // IntrNoMem for the compiler: the two empty asm statements are compiler-level fences that keep the LDS stores above in front
+    // of it and the reads of the other waves' s_wcnt[] behind it (no instruction, vmcnt untouched)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0), vmcnt / expcnt untouched
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     uint32_t bV = 0, bS = 0, nV = 0, nS = 0; // this wave's first slot in each list, list lengths (all wave-uniform)
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) {
@@ -2366,7 +2435,10 @@ void k_shade(RenderArgs a) {
       return bv | bs;
     };
     bool skip_write = false;
-    if constexpr (MODE == 2) {
+    if constexpr (APPROX) {
+      dense_passes(ApproxMath{}, true);
+      __syncthreads();
+    } else if constexpr (MODE == 2) {
       if (STATS && tid == 0) atomicAdd(&ap->stats[ST_DBG_IEEE_TILES], 1ull);
       dense_passes(IeeeMath{}, true);
       __syncthreads();
@@ -2481,12 +2553,32 @@ __global__ __launch_bounds__(256) void k_resolve8(const float *planes, uint8_t *
     o[2] = r2 | (b3 << 8) | (g3 << 16) | (r3 << 24);
   }
 }
+// Frames whose plane size rows * W is not a multiple of 4 pixels (odd sizes: the planes behind the first are not 16-byte
+// aligned and the 12-byte output groups would straddle frames): one pixel per thread, dword loads, byte stores — rare sizes,
+// same result
+__global__ __launch_bounds__(256) void k_resolve8_px(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W,
+                                                     uint64_t frame_stride) {
+  const uint64_t px_per_frame = (uint64_t)rows * W, total = px_per_frame * n_frames;
+  for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t f = q / px_per_frame, i = q - f * px_per_frame;
+    const SRZ_CAS float *p = as_const(planes + f * frame_stride + px_per_frame + i);
+    uint8_t *o = out + q * 3;
+    o[0] = (uint8_t)to_u8(p[0]), o[1] = (uint8_t)to_u8(p[px_per_frame]), o[2] = (uint8_t)to_u8(p[2 * px_per_frame]);
+  }
+}
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s) {
-  const uint64_t total = (uint64_t)n_frames * rows * W / 4;
-  if (!total) return;
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_resolve8, dim3(grid), dim3(256), 0, s, planes, out, n_frames, rows, W, frame_stride);
+  const uint64_t px = (uint64_t)n_frames * rows * W;
+  if (!px) return;
+  // the 4-pixel kernel walks a frame's plane as one flat run: it needs rows * W % 4 == 0 (then every plane and every frame starts
+  // on a 16-byte boundary of a 16-byte aligned buffer, and every 12-byte output group on a 4-byte one) — not W % 4 == 0
+  if ((((uint64_t)rows * W) & 3u) == 0 && ((uintptr_t)planes & 15u) == 0 && ((uintptr_t)out & 3u) == 0) {
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((px / 4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_resolve8, dim3(grid), dim3(256), 0, s, planes, out, n_frames, rows, W, frame_stride);
+  } else {
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((px + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_resolve8_px, dim3(grid), dim3(256), 0, s, planes, out, n_frames, rows, W, frame_stride);
+  }
 }
 
 // ================================================================================================================
@@ -2498,8 +2590,8 @@ void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint3
 // ================================================================================================================
 template <typename U>
 __global__ __launch_bounds__(256) void k_deinterleave(const U *gathered, U *full, uint32_t world, uint32_t n_fp /* frames x planes */,
-                                                      uint32_t bands_per_rank, uint32_t row_units /* units per row */) {
-  const uint64_t band_units = (uint64_t)BAND * row_units, total = (uint64_t)n_fp * bands_per_rank * world * band_units;
+                                                      uint32_t bands_per_rank, uint32_t band_units_ /* units per 32-row band */) {
+  const uint64_t band_units = band_units_, total = (uint64_t)n_fp * bands_per_rank * world * band_units;
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t in_band = i % band_units, b = i / band_units; // b = (frame-plane, local band, rank) of the destination
     const uint32_t rank = (uint32_t)(b % world), lb = (uint32_t)((b / world) % bands_per_rank);
@@ -2509,16 +2601,23 @@ __global__ __launch_bounds__(256) void k_deinterleave(const U *gathered, U *full
 }
 void launch_deinterleave(const void *gathered, void *full, uint32_t world, uint32_t n_fp, uint32_t bands_per_rank, uint32_t row_bytes,
                          hipStream_t s) {
-  const bool wide = (row_bytes & 15u) == 0 && (((uintptr_t)gathered | (uintptr_t)full) & 15u) == 0;
-  const uint32_t unit = wide ? 16u : 4u, row_units = row_bytes / unit;
-  const uint64_t total = (uint64_t)n_fp * bands_per_rank * world * BAND * row_units;
+  // unit of the copy: what a BAND (32 rows) of row_bytes and both buffers are aligned to — 16, 4 or (8-bit images of a width that is
+  // not a multiple of 4) 1 byte
+  const uint32_t band_bytes = (uint32_t)BAND * row_bytes;
+  const uintptr_t al = (uintptr_t)gathered | (uintptr_t)full;
+  const uint32_t unit = ((band_bytes & 15u) == 0 && (al & 15u) == 0) ? 16u : ((band_bytes & 3u) == 0 && (al & 3u) == 0) ? 4u : 1u;
+  const uint32_t band_units = band_bytes / unit; // (k_deinterleave's row_units x BAND: it only ever uses the product)
+  const uint64_t total = (uint64_t)n_fp * bands_per_rank * world * band_units;
   if (!total) return;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
-  if (wide)
-    hipLaunchKernelGGL(k_deinterleave<u32x4>, dim3(grid), dim3(256), 0, s, (const u32x4 *)gathered, (u32x4 *)full, world, n_fp, bands_per_rank, row_units);
-  else
+  if (unit == 16u)
+    hipLaunchKernelGGL(k_deinterleave<u32x4>, dim3(grid), dim3(256), 0, s, (const u32x4 *)gathered, (u32x4 *)full, world, n_fp, bands_per_rank, band_units);
+  else if (unit == 4u)
     hipLaunchKernelGGL(k_deinterleave<uint32_t>, dim3(grid), dim3(256), 0, s, (const uint32_t *)gathered, (uint32_t *)full, world, n_fp, bands_per_rank,
-                       row_units);
+                       band_units);
+  else
+    hipLaunchKernelGGL(k_deinterleave<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t *)gathered, (uint8_t *)full, world, n_fp, bands_per_rank,
+                       band_units);
 }
 
 // Exhaustive check of the short exact sequences above against the IEEE expansions: all 2^32 bit patterns.
@@ -2667,7 +2766,7 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
   hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(256), 0, s, a);
 }
 
-void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, hipStream_t s) {
+void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, bool approx, hipStream_t s) {
   if (max_tiles == 0) return;
   // One stream: a LARGE grid (a tile or two per workgroup: in-order hand-out, one-tile tail).  Renders interleaved on several
   // streams (a.other_streams): a grid about as large as the machine's resident capacity, the workgroups striding through the
@@ -2682,6 +2781,13 @@ void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t 
   }
   // one FAST build per (light count, with / without BUMP or DISPLACEMENT batches) some frame of the set has:
   // fast_mask bit NL = plain, bit 8 + NL = with them
+  if (approx) { // the tolerance mode's builds (classify_frames sets only the plain bits for the frames they shade)
+    if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false, true>), grid, dim3(256), 0, s, a);
+    if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false, true>), grid, dim3(256), 0, s, a);
+    if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false, true>), grid, dim3(256), 0, s, a);
+    if (fast_mask & 16u) hipLaunchKernelGGL((k_shade<false, 4, false, true>), grid, dim3(256), 0, s, a);
+    fast_mask = 0;
+  }
   if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false>), grid, dim3(256), 0, s, a);
   if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false>), grid, dim3(256), 0, s, a);
   if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false>), grid, dim3(256), 0, s, a);

@@ -67,3 +67,41 @@ def test_multi_gpu_budget_of_the_default_eight_rank_run_fits_hbm():
     assert b["peak_bytes_estimate"] < 0.85 * b["hbm_bytes"]
     p = bench.predicted_exchange(b["shard_bytes_bgr8"], b["frames_per_step"])
     assert 5.0 < p["exchange_ms_at_xgmi_peak"] < 5.6 and 3.6e5 < p["frames_per_sec_if_exchange_bound"] < 4.1e5
+
+
+def test_emit_prints_one_short_last_line_and_keeps_the_full_record_beside_it(tmp_path, monkeypatch, capsys):
+    """the compact line stays below LINE_LIMIT even when fed round 4's full 21 KB record (the one the driver could not parse), is
+    the last thing on stdout, carries configs 3 / 4 / 5 as flat scalars of `roofline`, and the full record lands in the details file"""
+    sys.path.insert(0, REPO)
+    import bench
+    full = json.load(open(os.path.join(REPO, "profiles", "r04_bench_driver_args.json")))
+    extras = full.pop("configs")
+    full["value_unprimed"], full["ms_per_step_unprimed"] = 270000.0, 0.948
+    n8 = {"shard_render_ms": [0.123456] * 8, "max_over_mean": 1.03, "predicted_step_ms": {"planes": 3.5, "bgr8": 0.66},
+          "predicted_fps": {"planes": 1.0e4, "bgr8": 2.0e4}}
+    full["roofline"]["multi_gpu_emulated"] = {"spot_texture_1024": {"frames_per_gpu": 32, "N2": n8, "N4": n8, "N8": n8},
+                                              "spot_x16_texture_2048": {"frames_per_gpu": 8, "N8": n8},
+                                              "spot_x8_overdraw_4096": {"frames_per_gpu": 4, "N8": n8}}
+    for k in ("spot_texture_1024:approx", "spot_bunny_phong_1080p:approx", "spot_x8_overdraw_4096:approx"):
+        full["roofline"]["per_config"][k] = dict(full["roofline"]["per_config"]["spot_bunny_phong_1080p"])
+    monkeypatch.setattr(bench, "DETAILS", str(tmp_path / "bench_details.json"))
+    bench.emit(full, extras)
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT <= 6000, len(lines[0])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "value_unprimed", "ms_per_step_unprimed"):
+        assert k in d, k
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    for c in ("c3", "c4", "c5"):
+        assert r["frac_" + c] == r["per_config"][c]["frac"] and r["fps_" + c] > 0
+    assert len(r["multi_gpu_emulated"]["c2"]["N8"]["ms"]) == 8 and len(d["cpu_baseline"]["sample"]) <= 200
+    kept = json.load(open(tmp_path / "bench_details.json"))
+    assert len(kept["configs"]) == len(extras) >= 11 and kept["value"] == full["value"]
+    # a record that is too long still yields a parseable line: the nested tables go first, the flat scalars stay
+    full["roofline"]["per_config"] = {f"w{i}": dict(full["roofline"]["per_config"]["spot_bunny_phong_1080p"]) for i in range(80)}
+    bench.emit(full, extras)
+    line = capsys.readouterr().out.strip().splitlines()[-1]
+    assert len(line) < bench.LINE_LIMIT and "frac" in json.loads(line)["roofline"]

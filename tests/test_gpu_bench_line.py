@@ -1,7 +1,9 @@
-"""-m gpu: the default bench.py line (N = 1) as the driver runs it — one JSON line whose `roofline.per_config` carries every
-BASELINE GPU config, the README scene, the scope `draw`, the non-integer-exponent variant and the reference's own published
-protocol (`readme_loop`), whose `cpu_baseline` is measured in the same run, and whose PMC constants are either those of THIS
-tree's kernel sources or flagged stale."""
+"""-m gpu: the default bench.py line (N = 1) as the driver runs it — ONE compact JSON line (< 6 KB, the LAST line of stdout, so
+that the driver's parser keeps it whole: round 4's 21 KB line came back `parsed: null`) whose `roofline` carries every BASELINE GPU
+config as flat scalars (`frac_c3` ...) and in `per_config` (+ the README scene, the scope `draw`, the non-integer-exponent
+variant, the tolerance-mode rows and the reference's own published protocol `readme_loop`), the unprimed figure beside the
+primed one, the render-side multi-GPU term measured on this GPU, whose `cpu_baseline` is measured in the same run, and whose
+PMC constants are either those of THIS tree's kernels or flagged stale.  The full records are in bench_details.json."""
 import json
 import os
 import subprocess
@@ -13,29 +15,45 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_default_line_carries_every_config_in_the_part_the_driver_keeps():
+def test_default_line_is_short_last_and_carries_every_config():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SRZ_BENCH_FORCE_LAUNCHER")}
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-budget-s", "2"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    nonempty = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert nonempty and nonempty[-1].startswith('{"metric"'), r.stdout[-500:]          # nothing follows the line on stdout
+    assert sum(ln.startswith('{"metric"') for ln in nonempty) == 1
+    line = nonempty[-1]
+    assert len(line) < 6000, len(line)
+    d = json.loads(line)
     assert d["metric"] == "frames_per_sec" and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
-    assert d["config"]["workload"] == "spot_texture_1024" and d["config"]["frames_per_step"] == 256 and d["priming_steps"] == 19
+    assert d["config"]["workload"] == "spot_texture_1024" and d["config"]["frames_per_step"] == 256
+    # the arguments taken literally (W warm-up steps from idle, K timed) beside the steady-state figure
+    assert d["value"] > 0 and d["value_unprimed"] > 0 and d["ms_per_step_unprimed"] > 0 and d["priming_steps"] >= 19
     roof = d["roofline"]
-    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.2 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.2 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert 0.1 < roof["frac_unprimed"] < 1.0
     assert (roof["traffic"] is None) == bool(roof.get("traffic_stale"))          # fresh counters, or flagged — never silently old ones
+    for k in ("c3", "c4", "c5"):                                                  # flat scalars: what the driver's parser keeps
+        assert 0.05 < roof["frac_" + k] < 1.0 and roof["fps_" + k] > 0
     pc = roof["per_config"]
-    for w in ("spot_bunny_phong_1080p", "spot_x16_texture_2048", "spot_x8_overdraw_4096", "readme_spot_crate_1024",
-              "spot_texture_1024_p7.5", "spot_texture_1024:draw"):
+    for w in ("c3", "c4", "c5", "readme", "c2_p7.5", "c2:draw", "c2:approx", "c3:approx", "c5:approx"):
         assert "error" not in pc[w], pc[w]
-        assert pc[w]["frames_per_sec"] > 0 and 0.05 < pc[w]["frac"] < 1.0 and pc[w]["one_stream_us"]["shade"] > 0
-    loop = pc["readme_spot_crate_1024:readme_loop"]
+        assert pc[w]["fps"] > 0 and 0.05 < pc[w]["frac"] < 1.0 and pc[w]["us"][2] > 0
+    loop = pc["readme:readme_loop"]
     assert "error" not in loop, loop
-    p10, med, p90 = loop["draw_complete_ms_p10_median_p90"]
-    assert 0 < p10 <= med <= p90 < 5.0 and loop["frames"] == 1000 and loop["reference_published_draw_ms_median"] == 17.06
+    p10, med, p90 = loop["draw_ms_p10_med_p90"]
+    assert 0 < p10 <= med <= p90 < 5.0 and loop["frames"] == 1000 and loop["ref_published_draw_ms"] == 17.06
+    em = roof["multi_gpu_emulated"]
+    assert "error" not in em, em
+    for n in (2, 4, 8):
+        e = em["c2"][f"N{n}"]
+        assert len(e["ms"]) == n and min(e["ms"]) > 0 and 1.0 <= e["max_over_mean"] < 2.0
+        assert e["pred_ms"]["planes"] >= e["pred_ms"]["bgr8"] >= max(e["ms"]) * 0.999
+    assert len(em["c4"]["N8"]["ms"]) == 8 and len(em["c5"]["N8"]["ms"]) == 8
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and "sample" in cb
-    assert any(e.get("scope") == "readme_loop" for e in d["configs"]) and len(d["configs"]) >= 11
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and 0 < len(cb["sample"]) <= 200
+    full = json.load(open(os.path.join(REPO, "bench_details.json")))
+    assert any(e.get("scope") == "readme_loop" for e in full["configs"]) and len(full["configs"]) >= 11
+    assert abs(full["value"] - d["value"]) <= 1e-4 * full["value"]

@@ -306,3 +306,43 @@ def test_two_ranks_overlapped_exchange_equals_oracle():
     for p in procs:
         p.join(timeout=60)
     assert all(ok is True for _, ok in res), res
+
+
+@pytest.mark.parametrize("w,h,world", [(101, 67, 1), (101, 67, 3), (322, 70, 2), (37, 33, 1)])
+def test_device_resolve_and_bgr8_exchange_for_any_width(orc, w, h, world):
+    """srz_frameset_resolve8 and the 8-bit exchange's de-interleave used to refuse widths that are not a multiple of 4 (rows of W x 3
+    bytes that are no whole dwords): every size now resolves on the device — unsharded (the plane size decides between the 4-pixel
+    and the one-pixel kernel) and sharded (one GPU plays every rank; the byte-granular de-interleave restores the rows)"""
+    import srz
+    frames = [scenes.config3(i, w, h) for i in (2, 5)]
+    refs = [orc.draw(f)[1] for f in frames]
+    lay = parallel.shard_layout(h, 0, world)
+    rows = lay["local_rows"]
+    g8 = torch.zeros((world, len(frames), 1, rows, w * 3), dtype=torch.uint8, device="cuda")
+    planes = torch.zeros((world, len(frames), 4, rows, w), dtype=torch.float32, device="cuda")
+    keep = None
+    for r in range(world):
+        ctx = srz.Context(0, r, world)
+        fs = ctx.frameset(frames)
+        assert fs.local_rows == rows
+        s = torch.cuda.current_stream().cuda_stream
+        fs.render(planes[r].data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
+        fs.resolve8(planes[r].data_ptr(), g8[r].data_ptr(), g8[r].numel(), s)
+        torch.cuda.synchronize()
+        if r == 0:
+            keep = (ctx, fs)
+        else:
+            fs.close(), ctx.close()
+    ctx, fs = keep
+    if world == 1:
+        for i, ref in enumerate(refs):
+            assert np.array_equal(g8[0, i, 0].cpu().numpy().reshape(h, w, 3), orc.resolve8(tuple(ref))), (w, h, i)
+    else:
+        full8 = torch.zeros((len(frames), 1, lay["bands_per_rank"] * world * 32, w * 3), dtype=torch.uint8, device="cuda")
+        fs.deinterleave(g8.data_ptr(), full8.data_ptr(), abi.EXCHANGE_BGR8, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i, ref in enumerate(refs):
+            assert np.array_equal(full8[i, 0, :h].cpu().numpy().reshape(h, w, 3), orc.resolve8(tuple(ref))), (w, h, world, i)
+            host8 = fs.read_gathered_frame(g8.data_ptr(), i, abi.EXCHANGE_BGR8)
+            assert np.array_equal(host8, orc.resolve8(tuple(ref)))
+    fs.close(), ctx.close()

@@ -112,26 +112,28 @@ def test_pool_overflow_then_growth(ctx, orc, monkeypatch):
     serves the bands that do not fit through the ordered rasteriser and the next one finds the pool grown.  Both must equal the
     oracle."""
     ctx.set_option(abi.OPT_POOL_LAZY, 1)
-    w = h = 1024
-    n = 24
-    t = np.zeros(n, abi.TRI_DTYPE)
-    rng = np.random.default_rng(5)
-    for i in range(n):
-        t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
-    nn = rng.normal(size=(n, 3, 3))
-    t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
-    f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
-    rc, ref, _ = orc.draw(f)
-    assert rc == 0
-    fs = ctx.frameset([f])
-    out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
-    for it in range(3):
-        out.fill_(-1.0)
-        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        same(out[0].cpu().numpy(), ref, f"pool overflow, render {it}")
-    fs.close()
-    ctx.set_option(abi.OPT_POOL_LAZY, 0)
+    try:  # (the shared ctx must get its default back whatever an assertion below does)
+        w = h = 1024
+        n = 24
+        t = np.zeros(n, abi.TRI_DTYPE)
+        rng = np.random.default_rng(5)
+        for i in range(n):
+            t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
+        nn = rng.normal(size=(n, 3, 3))
+        t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+        f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
+        rc, ref, _ = orc.draw(f)
+        assert rc == 0
+        fs = ctx.frameset([f])
+        out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+        for it in range(3):
+            out.fill_(-1.0)
+            fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            same(out[0].cpu().numpy(), ref, f"pool overflow, render {it}")
+        fs.close()
+    finally:
+        ctx.set_option(abi.OPT_POOL_LAZY, 0)
     with pytest.raises(Exception):
         ctx.set_option(99, 1)
 
