@@ -841,7 +841,7 @@ def main():
 
     multi = None
     if not multi_path:
-        dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes)
+        dt, kt, per_step = time_single_gpu(case, args.steps, args.warmup, fence, args.lanes, unprimed=True)
     else:
         head_x = "bgr8" if args.exchange == "bgr8" else "planes"
         dt, kt, per_step, multi = time_multi_gpu(case, comm, dist, args.steps, args.warmup, fence, head_x,

@@ -140,7 +140,6 @@ struct IeeeMath {
   __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
   __device__ __forceinline__ float len2d(float a, float b) { return len2d_f64(a, b); }
-  __device__ __forceinline__ float div(float a, float b) { return a / b; }
 };
 struct FastMath {
   bool bad = false; // (the rare checks: division operands, pow_fast's rounding flag)
@@ -172,14 +171,14 @@ struct FastMath {
     return rcp_core(sqrt_core(d));
   }
   __device__ __forceinline__ float len2d(float a, float b) { return len2d_f64(a, b); }
-  __device__ __forceinline__ float div(float a, float b) { return a / b; }
 };
 // ApproxMath — the TOLERANCE mode (SRZ_OPT_APPROX_SHADE, opt-in; never the default): the arithmetic CLASS of the reference's own
 // x86 path, which shades with approximate instructions — _mm256_rcp_ps (include/shader/Shader.hpp:131, src/Tools.cpp:19,
 // include/loader/TextureLoader.hpp:99, src/Rasterizer.cpp:111: 12 bits) and SVML _mm256_pow_ps (include/shader/Shader.hpp:195) —
 // on the hardware's own: bare v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp), x^p = v_exp_f32(p * v_log_f32(x)), texel * (1/255), the
-// binary64 pieces of the scalar path (the attenuation distance, std::pow) in binary32.  Only k_shade's colour arithmetic takes it:
-// k_raster stays exact, so z, coverage and ownership are bit-identical to the oracle in this mode too.  Nothing can go out of a
+// binary64 pieces of the scalar path (the attenuation distance, std::pow) in binary32.  Only k_shade's LIGHTING arithmetic takes it
+// (normalisations, attenuation, the power, the texel's scaling): k_raster stays exact, so z, coverage and ownership are
+// bit-identical to the oracle in this mode too, and so do the barycentrics and everything interpolated with them.  Nothing can go out of a
 // "fast range" here — no operand tracking, no re-shade.  tests/test_gpu_approx.py states the tolerance.
 struct ApproxMath {
   __device__ __forceinline__ float div255(float a) { return a * (1.0f / 255.0f); }
@@ -187,11 +186,13 @@ struct ApproxMath {
     const float y = __builtin_amdgcn_rcpf(b);
     q0 = a0 * y, q1 = a1 * y, q2 = a2 * y;
   }
-  __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  // (the one reciprocal of the coverage arithmetic, tri_consts: EXACT — the barycentrics, hence depth, normals' and texture
+  // coordinates' interpolation, are the oracle's bits in this mode too: a texture coordinate one ulp off can round to the
+  // neighbouring texel, which no colour tolerance covers)
+  __device__ __forceinline__ float rcp(float x) { return rcp_rn(x); }
   __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return __builtin_amdgcn_rsqf(d); }
   __device__ __forceinline__ float len2d(float a, float b) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(a, a, b * b)); }
-  __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -378,7 +379,6 @@ __device__ __forceinline__ bool cover_v(const TriXY &t, float fx, float fy, floa
   return alpha > 0.0f && alpha < 1.0f && beta > 0.0f && beta < 1.0f && gamma > 0.0f && gamma < 1.0f;
 }
 // "S" semantics: insideTriangle + barycentric(scalar) + z (src/Rasterizer.cpp:11-70,473)
-template <class M = IeeeMath>
 __device__ __forceinline__ bool cover_s(const TriXY &t, float fx, float fy, float &alpha, float &beta, float &gamma,
                                         float &z) {
   float ABx = t.bx - t.ax, ABy = t.by - t.ay, BCx = t.cx - t.bx, BCy = t.cy - t.by, CAx = t.ax - t.cx, CAy = t.ay - t.cy;
@@ -387,13 +387,7 @@ __device__ __forceinline__ bool cover_s(const TriXY &t, float fx, float fy, floa
   bool inside = (e0 > 0 && e1 > 0 && e2 > 0) || (e0 < 0 && e1 < 0 && e2 < 0);
   float PAx = t.ax - fx, PAy = t.ay - fy, PBx = t.bx - fx, PBy = t.by - fy, PCx = t.cx - fx, PCy = t.cy - fy;
   float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
-  if constexpr (std::is_same<M, ApproxMath>::value) { // (k_shade's tolerance mode only: one reciprocal for both)
-    const float y = __builtin_amdgcn_rcpf(t.s_area);
-    alpha = aPBC * y, beta = aPCA * y;
-  } else {
-    alpha = aPBC / t.s_area, beta = aPCA / t.s_area;
-  }
-  gamma = 1.0f - alpha - beta;
+  alpha = aPBC / t.s_area, beta = aPCA / t.s_area, gamma = 1.0f - alpha - beta;
   z = alpha * t.z0 + beta * t.z1 + gamma * t.z2;
   return inside;
 }
@@ -1333,7 +1327,7 @@ __device__ __forceinline__ void shade_pixel_s(M &m, const FrameK &K, const Shade
   unpack_pos(m, f, a);
   const float fx = (float)x, fy = (float)y;
   float alpha, beta, gamma, zz;
-  cover_s<std::conditional_t<std::is_same<M, ApproxMath>::value, ApproxMath, IeeeMath>>(a.t, fx, fy, alpha, beta, gamma, zz);
+  cover_s(a.t, fx, fy, alpha, beta, gamma, zz);
   late_fetch(f, late, gamma);
   unpack_attr(f, a);
   float nx = alpha * a.n0x + beta * a.n1x + gamma * a.n2x;
