@@ -2,9 +2,11 @@
 """The one artefact of this path's OUTPUT that the reference repository holds: assets/phong_cow.gif (README.md:223-231), a
 screen capture (1280x720, 612 frames) of the PHONG spot scene of README.md:127-231 running in the reference's own window.
 It cannot pin the oracle bit for bit (a scaled, palette-quantised capture of a window of unknown size), but it is the only
-evidence that does not pass through our reading of the source: it fixes the image ORIENTATION (no y flip, no mirror), the
-silhouette of the mesh under the reference's view / projection / NDC chain, the sense of rotation, and the grey level /
-channel symmetry of the Blinn-Phong result.
+evidence that does not pass through our reading of the source: it fixes the silhouette of the mesh under the reference's view /
+projection / NDC chain, the sense of rotation, the grey level / channel symmetry of the Blinn-Phong result — and, through the
+grey levels INSIDE the silhouette (highlights, shaded side), how the image is turned: the capture is the render of the source
+as written ROTATED BY 180 DEGREES (both axes: the sign convention of an older vertex stage, w < 0 after projection, or a flip
+at display time — the capture cannot tell those two apart), not flipped in y and not mirrored.
 
   python tests/golden/gif_check.py extract     (needs /root/reference: writes tests/golden/phong_cow/frame_*.png, the
                                                 window area of a few frames — data, committed)
@@ -59,7 +61,32 @@ def iou(a, b):
     return float((a & b).sum()) / float((a | b).sum())
 
 
-def oracle_views(size=512, step=5):
+def _variant(tris, size, how):
+    """the post-MVP stream as an OLDER build of the reference might have produced it (hypotheses about the capture):
+    rot180 = x and y negated around the screen centre (w < 0 after projection, the GAMES101-style sign convention; the winding
+    is unchanged); flipy = the y flip src/Scene.cpp:330's comment promises (flipy_w: with the winding restored, i.e. front
+    faces drawn); mirrorx likewise.  The lighting then happens in THAT screen space, as the shaders mix screen-space positions
+    with world-space lights."""
+    t = tris.copy()
+    if how == "rot180":
+        t["pos"][:, :, 0] = size - t["pos"][:, :, 0]
+        t["pos"][:, :, 1] = size - t["pos"][:, :, 1]
+    elif how.startswith("flipy"):
+        t["pos"][:, :, 1] = size - t["pos"][:, :, 1]
+    elif how.startswith("mirrorx"):
+        t["pos"][:, :, 0] = size - t["pos"][:, :, 0]
+    if how.endswith("_w"):
+        for k in ("pos", "nrm", "uv"):
+            a = t[k][:, 1].copy()
+            t[k][:, 1] = t[k][:, 2]
+            t[k][:, 2] = a
+    return t
+
+
+VERTEX_HYPOTHESES = ("rot180", "flipy", "flipy_w", "mirrorx", "mirrorx_w")
+
+
+def oracle_views(size=512, step=5, how="as_written"):
     """the README PHONG scene through the oracle for every `step` degrees: {deg: (mask, grey, bbox aspect, BGR mean)}"""
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "software-rasterizer_amd"))
@@ -71,6 +98,8 @@ def oracle_views(size=512, step=5):
     out = {}
     for deg in range(0, 360, step):
         tris = scenes.mesh_stream(scenes.SPOT_OBJ, size, size, float(deg), (0, 0, 0), 0.3)
+        if how != "as_written":
+            tris = _variant(tris, float(size), how)
         f = abi.Frame(size, size, scenes.EYE, scenes.LIGHTS, [(abi.SHADER_PHONG, -1, tris)], abi.FUSED_CLEAR)
         rc, planes, _ = oracle.draw(f)
         assert rc == 0
@@ -81,47 +110,53 @@ def oracle_views(size=512, step=5):
     return out
 
 
+def _grey_corr(m, g, vm, vg):
+    both = m & vm
+    return float(np.corrcoef(g[both], vg[both])[0, 1]) if both.sum() > 100 else 0.0
+
+
+def _score(m, g, views, fn):
+    """best silhouette IoU over the rotation angle; among the angles within 0.03 of it, the best correlation of the grey levels
+    inside the common silhouette (where the highlights and the shaded side are: what tells a flip from a rotation — the mesh
+    is nearly mirror-symmetric, so the silhouette alone cannot) → (iou, angle of the best IoU, correlation, its angle)"""
+    ious = {d: iou(m, fn(v[0])) for d, v in views.items()}
+    d_best = max(ious, key=ious.get)
+    corr, d_corr = max((_grey_corr(m, g, fn(v[0]), fn(v[1])), d) for d, v in views.items() if ious[d] >= ious[d_best] - 0.03)
+    return ious[d_best], d_best, corr, d_corr
+
+
 def report():
     frames = load_frames()
     views = oracle_views()
-    rep = {"frames": {}, "note": "IoU of bounding-box-normalised silhouettes (96x96) of the GIF's window and of the oracle's render of the "
-           "README PHONG scene, maximised over the rotation angle (5 degree steps), for the oracle's image as rendered and flipped"}
+    rep = {"frames": {}, "note": "per frame of the capture and per hypothesis: IoU of the bounding-box-normalised silhouettes (96x96) maximised over "
+           "the rotation angle (5 degree steps), and the correlation of the grey levels inside the common silhouette at the best of the "
+           "angles within 0.03 of that IoU.  display_*: the oracle's image of the source AS WRITTEN, turned at display time; vertex_*: the "
+           "post-MVP positions turned (an older vertex stage), lit in that screen space"}
     orient = {"as_rendered": lambda x: x, "upside_down": lambda x: x[::-1], "mirrored": lambda x: x[:, ::-1], "rotated_180": lambda x: x[::-1, ::-1]}
+    vviews = {h: oracle_views(how=h) for h in VERTEX_HYPOTHESES}
+    ident = orient["as_rendered"]
     for i, a in frames.items():
         grey = a.mean(2)
         mask = grey > 40.0
         m, g, aspect = normalise(mask, grey)
-        score = {o: max((iou(m, fn(views[d][0])), d) for d in views) for o, fn in orient.items()}   # per orientation: (best IoU, angle)
-        # the silhouette alone cannot tell a mirror image from the opposite rotation angle (the mesh is nearly symmetric): among
-        # the orientations whose best IoU is within 0.01 of the maximum, the brightest region decides
-        hl_gif = np.unravel_index(np.argmax(_blur(g * m)), g.shape)
-
-        def highlight(o):
-            vm_, vg_ = orient[o](views[score[o][1]][0]), orient[o](views[score[o][1]][1])
-            return np.unravel_index(np.argmax(_blur(vg_ * vm_)), vg_.shape)
-
+        hyp = {"display_" + o: _score(m, g, views, fn) for o, fn in orient.items()}
+        hyp.update({"vertex_" + h: _score(m, g, vviews[h], ident) for h in VERTEX_HYPOTHESES})
+        score = {o: hyp["display_" + o] for o in orient}
         top = max(v[0] for v in score.values())
-        o_best = min((o for o in score if score[o][0] >= top - 0.01), key=lambda o: np.hypot(*(np.subtract(highlight(o), hl_gif))))
+        o_best = max((o for o in score if score[o][0] >= top - 0.01), key=lambda o: score[o][2])   # silhouette first, then the grey levels
         best = score[o_best][1]
         vm, vg, vaspect, bgr = views[best]
-        vm, vg = orient[o_best](vm), orient[o_best](vg)
-        hl_orc = highlight(o_best)
         rep["frames"][str(i)] = {
-            "best_orientation": o_best, "best_angle_deg": best, "iou": score[o_best][0],
+            "best_orientation": o_best, "best_angle_deg": best, "iou": score[o_best][0], "grey_corr": score[o_best][2],
+            "hypotheses": {h: {"iou": v[0], "angle_deg": v[1], "grey_corr": v[2], "grey_corr_angle_deg": v[3]} for h, v in hyp.items()},
             "best_iou_per_orientation": {o: {"iou": v[0], "angle_deg": v[1]} for o, v in score.items()},
             "iou_second_best_angle_apart": max(iou(m, orient[o_best](views[d][0])) for d in views if min((d - best) % 360, (best - d) % 360) >= 45),
             "bbox_aspect_gif": aspect, "bbox_aspect_oracle_square_frame": vaspect, "implied_window_w_over_h": aspect / vaspect,
             "mean_rgb_gif_in_silhouette": [float(a[..., c][mask].mean()) for c in range(3)],
-            "mean_bgr_oracle_in_silhouette": bgr,
-            "brightest_region_gif_xy": [hl_gif[1] / N, hl_gif[0] / N], "brightest_region_oracle_xy": [hl_orc[1] / N, hl_orc[0] / N]}
+            "mean_bgr_oracle_in_silhouette": bgr}
     angles = [rep["frames"][str(i)]["best_angle_deg"] for i in FRAMES]
     rep["rotation_deg_between_fixture_frames"] = [(angles[k + 1] - angles[k]) % 360 for k in range(len(angles) - 1)]
     return rep
-
-
-def _blur(x, k=9):
-    c = np.cumsum(np.cumsum(np.pad(x, ((k, 0), (k, 0))), 0), 1)
-    return c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]
 
 
 if __name__ == "__main__":

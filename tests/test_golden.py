@@ -59,11 +59,13 @@ def test_golden_sanity():
 def test_oracle_against_the_references_own_gif():
     """The only output of this path the reference repository holds: assets/phong_cow.gif (a screen capture of the README PHONG
     scene).  tests/golden/gif_check.py renders that scene through the oracle and compares bounding-box-normalised silhouettes
-    with four committed frames of the capture.  What holds: the silhouette (view / projection / NDC chain, model scale: IoU
-    >= 0.95 at the best rotation angle, no other angle 45+ degrees away comes within 0.15), the grey level and the equality
-    of the three channels.  What does NOT hold: the orientation — the capture shows the oracle's image turned upside down
-    (the source as it stands has no y flip although its comment says so, src/Scene.cpp:330; the capture is
-    older than the tree).  The test pins both facts."""
+    AND the grey levels inside them with four committed frames of the capture, under every cheap hypothesis about how an older
+    build could have turned the image.  What holds: the silhouette (view / projection / NDC chain, model scale: IoU >= 0.95
+    at the best rotation angle, no other angle 45+ degrees away comes within 0.15), the grey level and the equality of the three
+    channels, a steady rotation between the fixture frames — and the capture is the render of the source as written ROTATED BY
+    180 DEGREES: only that hypothesis (at display time or in the vertex stage: the capture cannot tell the two apart) reproduces
+    both the silhouette and the shading in all four frames.  The y flip that src/Scene.cpp:330's comment promises reproduces the
+    silhouette only (its shading correlates NEGATIVELY); as written and mirrored miss the silhouette.  DESIGN.md §3."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("gif_check", os.path.join(os.path.dirname(__file__), "golden", "gif_check.py"))
@@ -71,11 +73,19 @@ def test_oracle_against_the_references_own_gif():
     spec.loader.exec_module(gc)
     rep = gc.report()
     for i, fr in rep["frames"].items():
+        h = fr["hypotheses"]
         assert fr["iou"] >= 0.95, (i, fr["iou"])
-        assert fr["best_orientation"] in ("upside_down", "rotated_180"), (i, fr["best_orientation"])
-        assert fr["best_iou_per_orientation"]["as_rendered"]["iou"] < 0.85, i      # the as-written orientation does not match
+        assert fr["best_orientation"] == "rotated_180", (i, fr["best_orientation"])
+        for rot in ("display_rotated_180", "vertex_rot180"):                       # silhouette AND shading
+            assert h[rot]["iou"] >= 0.95 and h[rot]["grey_corr"] >= 0.2, (i, rot, h[rot])
+        for flip in ("display_upside_down", "vertex_flipy", "vertex_flipy_w"):     # silhouette only: the shading is the wrong way round
+            assert h[flip]["iou"] >= 0.95 and h[flip]["grey_corr"] < 0.0, (i, flip, h[flip])
+        for miss in ("display_as_rendered", "display_mirrored", "vertex_mirrorx", "vertex_mirrorx_w"):
+            assert h[miss]["iou"] < 0.85, (i, miss, h[miss])                       # the as-written orientation does not match
         assert fr["iou"] - fr["iou_second_best_angle_apart"] >= 0.15, i
         assert 0.9 < fr["implied_window_w_over_h"] < 1.1, i                        # a square window (README: 1024 x 1024)
         g, o = fr["mean_rgb_gif_in_silhouette"], fr["mean_bgr_oracle_in_silhouette"]
         assert abs(g[0] - g[1]) < 1 and abs(g[1] - g[2]) < 1 and o[0] == o[1] == o[2]   # kd = (1,1,1), white lights: grey
         assert abs(sum(g) / 3 - o[0]) < 12.0, (i, g, o)                            # (capture: 6-level palette + dithering)
+    # one steady rotation through the four fixture frames (150 GIF frames apart): the same sense, 20-30 degrees each
+    assert all(325 <= d <= 345 for d in rep["rotation_deg_between_fixture_frames"]), rep["rotation_deg_between_fixture_frames"]
