@@ -2110,8 +2110,6 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
 #define SRZ_STAGE_TRIS 96 // triangles of a tile's list k_shade stages in LDS (12 KB colours + 4 KB lists + 9 KB triangles: 6 workgroups per CU)
 #endif
 constexpr uint32_t STAGE_TRIS = SRZ_STAGE_TRIS, STAGE_SD = 16;
-constexpr uint32_t OWN_MAX = STAGE_TRIS - 2; // (see s_bm in k_shade: 2 triangles' worth of s_tri hold the owners' positions)
-static_assert(OWN_MAX * 2 <= 2 * 96, "the owners' positions (16 bits each) must fit the two triangles' space left free");
 // (s_tri doubles as the {pixel, index} pair list of tiles whose ids are triangle indices: 2 dwords per pixel of the tile)
 static_assert(SRZ_STAGE_TRIS * 6 * 16 >= 2 * 32 * 32 * 4, "SRZ_STAGE_TRIS: s_tri must hold a tile's 1024 {pixel, index} pairs (>= 86 triangles)");
 #ifndef SRZ_GENPOW_MINW
@@ -2153,11 +2151,6 @@ void k_shade(RenderArgs a) {
   __shared__ uint16_t s_bat[STAGE_TRIS];
   __shared__ __attribute__((aligned(16))) ShadeDescG s_sd[STAGE_SD];
   __shared__ uint32_t s_flag;                                           // "some operand left FastMath's range"
-  // lists longer than the stage (by_lp, > STAGE_TRIS entries: 14 % of the tiles of the spot x16 scene): one bit per list position
-  // that OWNS a pixel, the running count in front of every word (+ the total) — if at most OWN_MAX triangles own the tile's
-  // pixels (a 32 x 32 tile rarely shows more), only those are staged, by RANK among the owners, and the pixels' ids are
-  // renamed to ranks; the owners' positions by rank sit in the last 192 bytes of s_tri, which OWN_MAX triangles leave free
-  __shared__ uint32_t s_bm[LP_MAX / 32], s_pref[LP_MAX / 32 + 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2181,9 +2174,7 @@ void k_shade(RenderArgs a) {
     const uint32_t tpf = ap->n_local_bands * ap->tiles_x;
     // how the tile's ids name a pixel's owner: by position in the tile's triangle list (16-bit ids) — the list's triangles are
     // staged in LDS if they fit (by_lp && staged), else looked up per pixel (by_lp) — or by index in the frame (32-bit ids)
-    const bool by_lp = (x.y & WORK_LP) != 0u, short_list = by_lp && x.z <= STAGE_TRIS; // workgroup-uniform
-    const bool long_list = by_lp && !short_list;
-    bool staged = short_list; // (a long list: decided below, once its owners are counted)
+    const bool by_lp = (x.y & WORK_LP) != 0u, staged = by_lp && x.z <= STAGE_TRIS; // workgroup-uniform
     const SRZ_CAS uint32_t *tlist = as_const(ap->pool) + x.w;
     // ---- 1. this thread's 4 pixels: their owner ids (nothing but the entry is needed for the address: the load is in flight
     //         under the frame descriptor's scalar loads), and the indices of the list entries whose pieces it will stage
@@ -2206,7 +2197,7 @@ void k_shade(RenderArgs a) {
     }
     const uint32_t none = by_lp ? 0xffffu : NO_TRI, sbit = by_lp ? 0x8000u : S_CLASS_BIT; // (scalar)
     constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
-    const uint32_t n_pc = short_list ? x.z * 6u : 0u;
+    const uint32_t n_pc = staged ? x.z * 6u : 0u;
     uint32_t ti[PASSES];
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) { // (passes the list does not reach are skipped by a SCALAR branch: most lists fit the first)
@@ -2275,23 +2266,10 @@ void k_shade(RenderArgs a) {
     const uint32_t incl2 = wave_scan_add(cnt2);
     if (lane == 63) s_wcnt[wave] = incl2;
     if (tid == 0) s_flag = 0;
-    if (long_list) { // mark the list positions that own a pixel (the bitmap zeroed first: a raw barrier, the loads stay in flight)
-      if (tid < (int)(LP_MAX / 32)) s_bm[tid] = 0u;
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (idk[k] != none) {
-          const uint32_t pos = idk[k] & (LP_MAX - 1u);
-          (void)__hip_atomic_fetch_or(&s_bm[pos >> 5], 1u << (pos & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
     // ---- 1b. the tile's triangles → LDS by DMA: 16-byte piece q of list entry l per thread (six threads per triangle: coalesced
     //          96 bytes).  The pieces go from memory straight to LDS — the wave's 64 land one after the other at a wave-uniform
     //          base, which is s_tri's own order — and hold no registers while in flight, under the compaction below
-    if (short_list) {
+    if (staged) {
 #pragma unroll
       for (int k = 0; k < PASSES; ++k) {
         if (n_pc <= 256u * k) break; // scalar
@@ -2320,50 +2298,12 @@ void k_shade(RenderArgs a) {
     nV = (uint32_t)__builtin_amdgcn_readfirstlane((int)nV), nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)nS);
     if (sd_mine) s_sd[tid] = sd_reg;
     uint32_t *const s_ent2 = reinterpret_cast<uint32_t *>(s_tri); // ({pixel, index} pairs: tiles without staged triangles)
-    if (long_list) { // workgroup-uniform
-      // the owners counted: 16 lanes of wave 0 scan the bitmap's words
-      if (wave == 0) {
-        const uint32_t wbits = lane < (int)(LP_MAX / 32) ? s_bm[lane] : 0u, c = (uint32_t)__builtin_popcount(wbits);
-        const uint32_t incl = wave_scan_add(c);
-        if (lane < (int)(LP_MAX / 32)) s_pref[lane] = incl - c;
-        if (lane == (int)(LP_MAX / 32) - 1) s_pref[LP_MAX / 32] = incl;
-      }
-      __syncthreads();
-      const uint32_t n_own = s_pref[LP_MAX / 32];
-      if (n_own <= OWN_MAX) { // workgroup-uniform: stage the owners only, by rank
-        uint16_t *const s_ownpos = reinterpret_cast<uint16_t *>(s_tri + OWN_MAX * 6u);
-#pragma unroll
-        for (int h = 0; h < (int)(LP_MAX / 256); ++h) {
-          const uint32_t pos = (uint32_t)tid + 256u * h, wbits = s_bm[pos >> 5];
-          if ((wbits >> (pos & 31u)) & 1u) s_ownpos[s_pref[pos >> 5] + (uint32_t)__builtin_popcount(wbits & ((1u << (pos & 31u)) - 1u))] = (uint16_t)pos;
-        }
-        __syncthreads();
-        const uint32_t n_pc2 = n_own * 6u;
-#pragma unroll
-        for (int k = 0; k < PASSES; ++k) {
-          if (n_pc2 <= 256u * k) break; // scalar
-          const uint32_t pc = (uint32_t)tid + 256u * k;
-          if (pc < n_pc2) {
-            const uint32_t q = pc % 6u, t = tlist[s_ownpos[pc / 6u]];
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const f32x4 *>(ap->tris + tri_off + (t & PACK_IDX_MASK)) + q,
-                                             (__attribute__((address_space(3))) void *)(s_tri + (wave * 64 + 256 * k)), 16, 0, 0);
-            if (q == 0u) s_bat[pc / 6u] = (uint16_t)(t >> PACK_IDX_BITS);
-          }
-        }
-        staged = true;
-      }
-    }
     {
       uint32_t oV = bV + ((incl2 - cnt2) & 0xffffu), oS = nV + bS + ((incl2 - cnt2) >> 16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bool own = idk[k] != none, isS = own && (idk[k] & sbit) != 0;
-        uint32_t owner = idk[k] & ~sbit;
-        if (long_list && staged && own) { // position in the list → rank among the owners
-          const uint32_t wbits = s_bm[owner >> 5];
-          owner = s_pref[owner >> 5] + (uint32_t)__builtin_popcount(wbits & ((1u << (owner & 31u)) - 1u));
-        }
-        const uint32_t o = isS ? oS : oV;
+        const uint32_t o = isS ? oS : oV, owner = idk[k] & ~sbit;
         if (own) {
           if (by_lp)
             s_ent[o] = (uint32_t)(p0 + k) | (owner << PIX_BITS);
