@@ -51,7 +51,8 @@ EXTRA_CASES = [("spot_bunny_phong_1080p", 128, 20), ("spot_x16_texture_2048", 12
 # workloads whose summary goes into roofline.per_config (the part of the line the driver's parser keeps): BASELINE configs 3 / 4 / 5,
 # the scene of the reference's one published figure, configs[1] at scope draw, the exponent variant the generic build used to serve
 # (workload, frames per step, steps) rendered once more in the tolerance mode (SRZ_OPT_APPROX_SHADE): `<workload>:approx` rows
-APPROX_CASES = [("spot_texture_1024", 256, 10), ("spot_bunny_phong_1080p", 128, 10), ("spot_x8_overdraw_4096", 64, 10)]
+APPROX_CASES = [("spot_texture_1024", 256, 10), ("spot_bunny_phong_1080p", 128, 10), ("spot_x16_texture_2048", 128, 10),
+                ("spot_x8_overdraw_4096", 64, 10)]
 PER_CONFIG = ("spot_bunny_phong_1080p", "spot_x16_texture_2048", "spot_x8_overdraw_4096", "readme_spot_crate_1024", "spot_texture_1024_p7.5")
 HBM_BYTES = 288e9  # per MI355X
 PRIME_TO = 20      # untimed renders in front of every timed region, the --warmup steps included (time_single_gpu)
@@ -711,7 +712,8 @@ def emit(res, extras):
     line = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                     "vs_baseline", "dtype", "data")}
     line["config"] = res["config"]
-    line.update({k: res.get(k) for k in ("priming_steps", "value_unprimed", "ms_per_step_unprimed", "mfragments_per_sec", "ms_per_step_p10_median_p90")})
+    line.update({k: res.get(k) for k in ("priming_steps", "value_unprimed", "ms_per_step_unprimed", "mfragments_per_sec", "fragments_per_frame",
+                                         "visible_pixels_per_frame", "ms_per_step_p10_median_p90")})
     line["roofline"] = r
     v = res.get("valu")
     line["valu"] = {k: v.get(k) for k in ("valu_frac", "valu_pipe_frac_est", "valu_per_64_visible_px")} if v else None

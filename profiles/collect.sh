@@ -15,6 +15,9 @@ SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WA
 # instruction classes (what a VALU instruction costs the pipe: plain 2 cycles, binary64 4, transcendental 8) and resident waves per SIMD
 MIX="SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32"
 python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.log || exit 1
+cp bench_details.json $OUT/bench_plain_details.json
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.log || exit 1
+cp bench_details.json $OUT/bench_driver_args_details.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes -- python3 bench.py --no-cpu-baseline --no-extras > $OUT/bench_traced_lanes.json 2> $OUT/trace_lanes.log || exit 1
 # workload : frames per step (= bench.py's EXTRA_CASES and its default)
 for wf in spot_texture_1024:256 spot_bunny_phong_1080p:128 spot_x16_texture_2048:128 spot_x8_overdraw_4096:64 readme_spot_crate_1024:256 \

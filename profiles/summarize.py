@@ -134,3 +134,6 @@ counters["_kernel_source_hash"] = out["kernel_source_hash"] = _h or bench.kernel
 json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump(counters, open(counters_file, "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_plain.json"), os.path.join(here, f"{tag}_bench.json"))
+for extra in ("bench_plain_details.json", "bench_driver_args.json", "bench_driver_args_details.json"):  # (the full records beside the compact lines)
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(here, f"{tag}_{extra}"))

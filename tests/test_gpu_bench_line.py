@@ -38,7 +38,7 @@ def test_default_line_is_short_last_and_carries_every_config():
     for k in ("c3", "c4", "c5"):                                                  # flat scalars: what the driver's parser keeps
         assert 0.05 < roof["frac_" + k] < 1.0 and roof["fps_" + k] > 0
     pc = roof["per_config"]
-    for w in ("c3", "c4", "c5", "readme", "c2_p7.5", "c2:draw", "c2:approx", "c3:approx", "c5:approx"):
+    for w in ("c3", "c4", "c5", "readme", "c2_p7.5", "c2:draw", "c2:approx", "c3:approx", "c4:approx", "c5:approx"):
         assert "error" not in pc[w], pc[w]
         assert pc[w]["fps"] > 0 and 0.05 < pc[w]["frac"] < 1.0 and pc[w]["us"][2] > 0
     loop = pc["readme:readme_loop"]
