@@ -115,6 +115,10 @@ struct srz_frameset {
   bool any_generic = true;  // some frame needs the generic build
   uint32_t *d_vis = nullptr, *d_work_count = nullptr, *d_chunk_rows = nullptr; // d_vis: the per-tile pixel lists (srz_device.h)
   uint4 *d_worklist = nullptr;
+  // k_shade's work lists are stored only for the build kinds some frame of the set needs (+ the generic one): slot of kind k =
+  // (kind_slots >> 4k) & 15 (RenderArgs::kind_slots); a re-classification that brings a new kind in grows the storage
+  uint64_t kind_slots = 0;
+  uint32_t kind_mask = 0, n_kind_slots = 0;
   bool approx_shade = false; // SRZ_OPT_APPROX_SHADE at creation: frames of 1..4 lights without BUMP / DISPLACEMENT batches are shaded by the ApproxMath builds
   bool no_packed = false; // SRZ_NO_PACKED (tests): no frame is FD_PACKED — 32-bit owner ids by triangle index, no staged triangles
   uint32_t *d_band_desc = nullptr; // the band sort of k_setup / k_chunks (srz_device.h, GROUP_TRIS): descriptors [group][local band]
@@ -203,6 +207,36 @@ void classify_frames(srz_frameset *fs) {
   }
 }
 
+// the build kinds (srz_device.h: SHADE_KIND_*) the classified frames send tiles to, as a bit mask; the generic kind always (counting
+// runs and SRZ_ORDERED... send everything there)
+uint32_t kinds_needed(const srz_frameset *fs) {
+  uint32_t m = 1u << SHADE_KIND_GENERIC;
+  for (uint32_t nl = 1; nl <= 4; ++nl) {
+    if (fs->fast_mask & (1u << nl)) m |= 1u << (nl - 1u);
+    if (fs->fast_mask & (1u << (8u + nl))) m |= 1u << (nl - 1u + 4u);
+    if (fs->fast_mask & (1u << (16u + nl))) m |= 1u << (nl - 1u + 8u);
+  }
+  return m;
+}
+// (re)allocates the work-list storage when the set needs a kind that has no slot yet; hipSuccess when nothing had to change
+hipError_t ensure_worklists(srz_frameset *fs) {
+  const uint32_t need = kinds_needed(fs) | fs->kind_mask;
+  if (need == fs->kind_mask && fs->d_worklist) return hipSuccess;
+  if (fs->d_worklist) { // renders in flight may still be walking the old lists
+    (void)hipDeviceSynchronize();
+    (void)hipFree(fs->d_worklist);
+    fs->d_worklist = nullptr;
+  }
+  uint64_t slots = 0;
+  uint32_t n = 0;
+  for (uint32_t k = 0; k <= SHADE_KIND_GENERIC; ++k)
+    if (need & (1u << k)) slots |= (uint64_t)(n++) << (4u * k);
+  const size_t cap = (size_t)(fs->n_frames < 8 ? fs->n_frames : (fs->n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x;
+  const hipError_t e = hipMalloc((void **)&fs->d_worklist, std::max<size_t>(sizeof(uint4) * 8u * n * cap, 256));
+  if (e == hipSuccess) fs->kind_mask = need, fs->kind_slots = slots, fs->n_kind_slots = n;
+  return e;
+}
+
 void free_frameset_buffers(srz_frameset *fs) {
   for (int i = 0; i < srz_frameset::STAGE_RING; ++i) {
     if (fs->h_stage[i]) (void)hipHostFree(fs->h_stage[i]);
@@ -264,6 +298,7 @@ RenderArgs make_args(const srz_ctx *ctx, const srz_frameset *fs, float *d_out, u
   a.sdesc = fs->d_sdesc;
   a.vis = fs->d_vis;
   a.worklist = fs->d_worklist;
+  a.kind_slots = fs->kind_slots;
   a.work_count = fs->d_work_count;
   // (a list holds the tiles of every 8th frame; of fewer than 8 frames: any of them)
   a.work_cap = (uint32_t)(fs->n_frames < 8 ? fs->n_frames : (fs->n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x;
@@ -784,7 +819,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     FS_TRY(dev_alloc((void **)&fs->d_redo_list, sizeof(uint4) * fs->max_tiles));
   }
   FS_TRY(dev_alloc((void **)&fs->d_vis, sizeof(uint32_t) * (size_t)fs->max_tiles * ((size_t)TILE * TILE)));
-  FS_TRY(dev_alloc((void **)&fs->d_worklist, sizeof(uint4) * N_WORK_LISTS * (size_t)(n_frames < 8 ? n_frames : (n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x));
+  FS_TRY(ensure_worklists(fs)); // (8 lists per build kind the classified frames need: not all 104)
   FS_TRY(dev_alloc((void **)&fs->d_work_count, sizeof(uint32_t) * CNT_STRIDE * N_WORK_LISTS));
   FS_TRY(dev_alloc((void **)&fs->d_sdesc, sizeof(ShadeDescG) * fs->h_batches.size()));
   FS_TRY(hipMemcpy(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
@@ -943,6 +978,7 @@ int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *f
     }
   }
   classify_frames(fs);
+  if (ensure_worklists(fs) != hipSuccess) return fail(ctx, SRZ_E_NOMEM, "srz_sceneset_update: hipMalloc of the work lists failed");
   // one asynchronous copy on the context's stream: ordered after every render already submitted there (which may still
   // be reading the descriptors) and before the next one.  Renders submitted on OTHER streams are the caller's to order.
   const unsigned slot = fs->stage_next++ % srz_frameset::STAGE_RING;
@@ -1423,6 +1459,7 @@ static int refresh_plain_frame(srz_ctx *ctx, srz_frameset *fs, const srz_frame &
   d.p = fr.p, d.kh = fr.kh, d.kn = fr.kn;
   d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER);
   classify_frames(fs);
+  if (ensure_worklists(fs) != hipSuccess) return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc of the work lists failed");
   HIP_TRY(ctx, hipMemcpyAsync(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   if (fr.n_lights) HIP_TRY(ctx, hipMemcpyAsync(fs->d_lights, fr.lights, sizeof(srz_light) * fr.n_lights, hipMemcpyHostToDevice, s));
   size_t o = 0;

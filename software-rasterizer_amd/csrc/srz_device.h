@@ -148,10 +148,12 @@ struct RenderArgs {
   uint32_t *vis;                 // owner ids per tile [frame][local band][tile x][PIX_SLOT dwords]: 16 bits per pixel (position in
                                  // the tile's triangle list) or 32 (index in the frame) — written by the rasterisers' write-out for
                                  // tiles that have an owner, read by k_shade (srz_kernels.hip, PIX_SLOT)
-  // k_shade's work: N_WORK_LISTS lists [build: FAST for 1..4 lights (3 forms), generic][frame % 8] of the tiles that have an owner, as
+  // k_shade's work: 8 lists [frame % 8] per build kind in use (FAST for 1..4 lights in 3 forms, generic) of the tiles that have an owner, as
   // {frame * tiles_per_frame + (lb*tiles_x + tx), flags, list entries, list offset} (srz_kernels.hip, work_append), in arrival
   // order; work_cap entries each
   uint4 *worklist;
+  uint64_t kind_slots;           // storage slot of build kind k in worklist[]: (kind_slots >> 4k) & 15 — lists exist only for the kinds the
+                                 // set's frames need (the counters in work_count[] are indexed by kind, all of them exist)
   uint32_t *work_count;          // [list * CNT_STRIDE]: word 0 = entries (zeroed by k_setup, bumped by k_raster), word 1 = k_shade's cursor
   uint32_t work_cap;
   uint32_t tiles_x, n_local_bands, n_frames;

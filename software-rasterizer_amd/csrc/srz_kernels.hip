@@ -1208,8 +1208,9 @@ __device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_
   const uint32_t kind = (!a.force_generic && (frame_flags & FD_FAST_SHADE) != 0u)
                             ? ((frame_flags >> FD_NL_SHIFT) & 7u) - 1u + ((frame_flags & FD_BUMPY) ? 4u : 0u) + ((frame_flags & FD_GENPOW) ? 8u : 0u)
                             : SHADE_KIND_GENERIC;
-  const uint32_t L = kind * 8u + ((a.n_frames >= 8u ? frame : frame + entry) & 7u);
-  a.worklist[(size_t)L * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(frame, lb | (tx << 10) | wflags, list_cnt, list_off);
+  const uint32_t sub = (a.n_frames >= 8u ? frame : frame + entry) & 7u, L = kind * 8u + sub;
+  const uint32_t Ls = ((uint32_t)(a.kind_slots >> (4u * kind)) & 15u) * 8u + sub; // (the kind's slot in the lists' storage)
+  a.worklist[(size_t)Ls * a.work_cap + atomicAdd(&a.work_count[L * CNT_STRIDE], 1u)] = make_uint4(frame, lb | (tx << 10) | wflags, list_cnt, list_off);
 }
 
 // bit 31 of an owner id: the pixel lies in the scalar-tail ("S") columns of its owner's bounding box
@@ -2487,8 +2488,9 @@ void k_shade(RenderArgs a) {
   // frames of 1024^2: a persistent grid of 4096 workgroups dealing every 128th tile of a frame 0.78 ms (one stream), a
   // persistent grid drawing tiles from atomic cursors the same on one stream but 7 % slower on two (it holds every CU slot to
   // its end), this walk 0.73 ms.
-  const uint32_t L = (FAST ? (uint32_t)(light_count<FASTNL>() - 1) + (BUMPY ? 4u : 0u) + (GENPOW ? 8u : 0u) : SHADE_KIND_GENERIC) * 8u + (blockIdx.x & 7u);
-  const SRZ_CAS u32x4 *list = reinterpret_cast<const SRZ_CAS u32x4 *>(as_const(a.worklist)) + (size_t)L * a.work_cap;
+  constexpr uint32_t KIND = FAST ? (uint32_t)(light_count<FASTNL>() - 1) + (BUMPY ? 4u : 0u) + (GENPOW ? 8u : 0u) : SHADE_KIND_GENERIC;
+  const uint32_t L = KIND * 8u + (blockIdx.x & 7u), Ls = ((uint32_t)(a.kind_slots >> (4u * KIND)) & 15u) * 8u + (blockIdx.x & 7u);
+  const SRZ_CAS u32x4 *list = reinterpret_cast<const SRZ_CAS u32x4 *>(as_const(a.worklist)) + (size_t)Ls * a.work_cap;
   // the list's length and this workgroup's first entry are loaded TOGETHER (the entry's index is clamped into the list's
   // storage; it is used only if it lies below the length): one round trip instead of two before the tile's own loads start
   uint32_t w = blockIdx.x >> 3;
