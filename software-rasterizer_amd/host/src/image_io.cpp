@@ -1,7 +1,8 @@
 // image_io.cpp — decode an image file to what cv::imread(path) (default flags) gives the reference's TextureLoader
 // (src/TextureLoader.cpp:3-12): 8-bit, 3 channels, BGR order, alpha dropped, top row first.
-// OpenCV is absent from this image; PNG (the format of every raster-path asset) is decoded here with zlib, plus
-// binary PPM (P6) for tools.  Unsupported input → std::runtime_error, like an empty cv::Mat does in the reference.
+// OpenCV is absent from this image; PNG (the textures of the raster path) is decoded here with zlib, JPEG (the height map of the
+// bump / displacement shaders, examples/models/spot/hmap.jpg) in jpeg_decode.cpp, plus binary PPM (P6) for tools.  Unsupported
+// input → std::runtime_error, like an empty cv::Mat does in the reference.
 #include <zlib.h>
 
 #include <cstdint>
@@ -148,10 +149,14 @@ static void decode_ppm(const std::vector<uint8_t> &d, const std::string &path, s
   for (size_t i = 0; i < (size_t)W * H; ++i) bgr[i * 3] = d[p + i * 3 + 2], bgr[i * 3 + 1] = d[p + i * 3 + 1], bgr[i * 3 + 2] = d[p + i * 3];
 }
 
+void decode_jpeg(const std::vector<uint8_t> &d, const std::string &path, std::vector<uint8_t> &bgr, int &W, int &H); // jpeg_decode.cpp
+
 void load_image_bgr(const std::string &path, std::vector<uint8_t> &bgr, int &W, int &H) {
   std::vector<uint8_t> d = read_file(path);
   if (d.size() >= 2 && d[0] == 'P' && d[1] == '6')
     decode_ppm(d, path, bgr, W, H);
+  else if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8 && d[2] == 0xff)
+    decode_jpeg(d, path, bgr, W, H);
   else
     decode_png(d, path, bgr, W, H);
 }

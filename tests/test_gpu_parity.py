@@ -235,6 +235,23 @@ def test_bump_and_displacement(ctx, orc, shader):
     assert (gpu[1] == 255.0).any()       # the 8-wide columns are the reference's empty SIMD stubs: white
 
 
+@pytest.mark.parametrize("shader", [abi.SHADER_BUMP, abi.SHADER_DISPLACEMENT])
+def test_bump_with_the_height_map_the_reference_ships(ctx, orc, shader):
+    """examples/models/spot/hmap.jpg (a progressive JPEG, copied to assets/) is what the reference's bump / displacement shaders
+    are meant to sample: decoded by the C++ host layer's own JPEG decoder (libjpeg-turbo's bytes: tests/test_host_layer.py),
+    uploaded as texture 5, the same bytes given to the oracle"""
+    import os
+    from srz import host
+    hm = host.load_image_bgr(os.path.join(os.path.dirname(scenes.SPOT_OBJ), "hmap.jpg"))
+    assert hm.shape == (800, 800, 3)
+    orc.texture_set(5, hm)
+    ctx.texture_upload(5, hm)
+    f0 = scenes.config2(6, size=512)
+    f = abi.Frame(512, 512, scenes.EYE, scenes.LIGHTS, [(shader, 5, f0.tris[0])], abi.FUSED_CLEAR)
+    gpu, ref = run_both(ctx, orc, f)
+    compare(gpu, ref, f"hmap.jpg shader {shader}")
+
+
 def test_small_texture_and_uv_clamps(ctx, orc):
     rng = np.random.default_rng(3)
     tex = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)

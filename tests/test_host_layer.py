@@ -59,6 +59,69 @@ def test_png_decoder_rejects_malformed_headers(tmp_path):
             host.load_image_bgr(str(p))
 
 
+def test_jpeg_decoder_against_libjpeg_turbo_fixtures():
+    """cv::imread reads JPEG through libjpeg(-turbo) with default settings; the C++ decoder (jpeg_decode.cpp: T.81 baseline +
+    progressive, libjpeg's ISLOW inverse DCT, fancy upsampling and colour tables) must return the same bytes.  Expected pixels:
+    tests/golden/jpeg/expected.npz, made by tests/golden/make_jpeg_golden.py with Pillow (libjpeg-turbo) in this image — for ten
+    small synthetic files and for the height map the reference ships for BUMP / DISPLACEMENT (assets/models/spot/hmap.jpg:
+    800 x 800, progressive, 4:2:0)."""
+    import zlib
+    gold = os.path.join(REPO, "tests", "golden", "jpeg")
+    exp = np.load(os.path.join(gold, "expected.npz"))
+    names = [n for n in exp.files if not n.startswith("hmap_")]
+    assert len(names) == 10
+    for n in names:
+        got = host.load_image_bgr(os.path.join(gold, n + ".jpg"))
+        assert got.shape == exp[n].shape and np.array_equal(got, exp[n]), n
+    hm = host.load_image_bgr(os.path.join(REPO, "assets", "models", "spot", "hmap.jpg"))
+    assert list(hm.shape) == exp["hmap_shape"].tolist() == [800, 800, 3]
+    assert zlib.crc32(hm.tobytes()) == int(exp["hmap_crc32"][0])
+    assert np.array_equal(hm[384:416, 384:416], exp["hmap_centre"])
+    assert np.array_equal(hm.reshape(-1, 3)[exp["hmap_idx"]], exp["hmap_samples"])
+
+
+def test_jpeg_decoder_live_against_pillow(tmp_path):
+    """the same comparison on files written now (sizes down to 1 x 1, every subsampling, optimised tables, restart markers)"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(7)
+    n = 0
+    for (w, h) in ((1, 1), (2, 5), (17, 13), (64, 48), (250, 3)):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        a[:, : w // 2] = (np.arange(h)[:, None, None] * 255 // max(h - 1, 1)).astype(np.uint8)   # half smooth, half noise
+        for mode, subs in (("RGB", (0, 1, 2)), ("L", (None,))):
+            for sub in subs:
+                for prog in (False, True):
+                    for extra in ({}, {"optimize": True, "quality": 35}, {"restart_marker_blocks": 2, "quality": 97}):
+                        p = str(tmp_path / f"j{n}.jpg")
+                        kw = dict(format="JPEG", progressive=prog, **extra)
+                        if sub is not None:
+                            kw["subsampling"] = sub
+                        Image.fromarray(a if mode == "RGB" else a[:, :, 0], mode).save(p, **kw)
+                        expect = np.asarray(Image.open(p).convert("RGB"), np.uint8)[:, :, ::-1]
+                        assert np.array_equal(host.load_image_bgr(p), expect), (w, h, mode, sub, prog, extra)
+                        n += 1
+    assert n == 120
+
+
+def test_jpeg_decoder_rejects_what_it_does_not_decode(tmp_path):
+    """truncated files, a frame header of an unsupported process (arithmetic coding, 12-bit, CMYK) and garbage after SOI raise
+    the loader's error (an empty cv::Mat in the reference → its runtime_error), they do not crash the host process"""
+    good = open(os.path.join(REPO, "tests", "golden", "jpeg", "base_444_64.jpg"), "rb").read()
+    sof = good.index(b"\xff\xc0")
+    cases = {"no_frame": good[:sof], "arith": good[:sof] + b"\xff\xc9" + good[sof + 2:], "bits12": good[:sof + 4] + b"\x0c" + good[sof + 5:],
+             "cmyk": good[:sof + 9] + b"\x04" + good[sof + 10:], "soi_only": b"\xff\xd8\xff", "truncated_seg": good[:sof + 6]}
+    for name, data in cases.items():
+        p = tmp_path / f"{name}.jpg"
+        p.write_bytes(data)
+        with pytest.raises(RuntimeError):
+            host.load_image_bgr(str(p))
+    # a file cut inside its entropy-coded data still decodes (libjpeg pads with zeros and warns): same size, top rows intact
+    cut = tmp_path / "cut.jpg"
+    cut.write_bytes(good[:len(good) * 2 // 3])
+    a, b = host.load_image_bgr(str(cut)), host.load_image_bgr(os.path.join(REPO, "tests", "golden", "jpeg", "base_444_64.jpg"))
+    assert a.shape == b.shape and np.array_equal(a[:16], b[:16])
+
+
 @pytest.mark.parametrize("path", [pscenes.SPOT_OBJ, pscenes.BUNNY_OBJ])
 def test_obj_loader_matches_the_restatement(path):
     v_ref, f_ref = oscenes.mesh(path)
