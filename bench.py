@@ -932,6 +932,8 @@ def main():
                 d, k, ps = time_single_gpu(c, s, 15 if w == args.workload else 8, fence, n_lanes)
                 extras.append(case_record(c, s, d, k, ps, c.stats["fragments"], c.stats["visible"]))
                 extras[-1]["approx_shade"] = bool(approx)
+                if approx:
+                    extras[-1]["valu"] = None  # (the instruction counters in profiles/ are the exact builds')
                 c.close()
             except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
                 extras.append({"workload": w, "scope": scope, "error": str(e)[:200]})

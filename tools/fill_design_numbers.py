@@ -1,13 +1,13 @@
-"""dev tool: (re)write the numbers table of DESIGN.md §5 from a bench.py JSON line (default: profiles/r04_bench_driver_args.json);
-the table sits between the markers <!-- numbers:begin --> and <!-- numbers:end -->"""
+"""dev tool: (re)write the numbers table of DESIGN.md §5 from the FULL record of a bench.py run (bench_details.json; default:
+profiles/r05_bench_driver_args_details.json); the table sits between the markers <!-- numbers:begin --> and <!-- numbers:end -->"""
 import json
 import os
 import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r04_bench_driver_args.json")
-d = json.loads(open(src).read().strip().splitlines()[-1])
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r05_bench_driver_args_details.json")
+d = json.load(open(src))
 NAMES = {"spot_bunny_phong_1080p": "3 spot + bunny PHONG 1920×1080", "spot_x16_texture_2048": "4 spot ×16 TEXTURE 2048²",
          "spot_x8_overdraw_4096": "5 overdraw ×8 NORMAL/PHONG 4096²", "readme_spot_crate_1024": "README scene: spot + Crate1.obj 1024²",
          "spot_texture_1024_3lights": "2 with 3 lights", "spot_texture_1024_p32": "2 with p = 32",
@@ -31,10 +31,14 @@ for e in d["configs"]:
         loop = e
     elif "error" not in e:
         nm = NAMES.get(e["workload"]) or ("2, scope `draw` (vertex stage timed)" if e["scope"] == "draw" else "2, one frameset on one stream")
+        if e.get("approx_shade"):
+            nm = (NAMES.get(e["workload"]) or "2 spot TEXTURE 1024²").split(" (")[0] + " — tolerance mode"
         out.append(row(nm, e))
 txt = "\n".join(out)
-txt += (f"\n\n(`python bench.py --steps {d['steps']} --warmup {d['warmup']}`, `profiles/{os.path.basename(src)}`; round 3 with the driver's arguments: "
-        "247 200 frames/s / 0.549, configs 3 / 4 / 5 0.484 / 0.338 / 0.340, p = 7.5 175 300.)  The reference's own protocol through the C++ API "
+txt += (f"\n\n(`python bench.py --steps {d['steps']} --warmup {d['warmup']}`, `profiles/{os.path.basename(src)}`; `value` is the second timed region; the first one, "
+        f"straight after the {d['warmup']} warm-up steps from idle: {d['value_unprimed']:,.0f} frames/s / {d['roofline']['algorithmic_bytes_per_launch'] / (d['ms_per_step_unprimed'] * 1e-3) / 8e12:.3f}.  "
+        "Round 4 with the driver's arguments: 287 000 frames/s / 0.641, configs 3 / 4 / 5 0.593 / 0.406 / 0.415; round 3: 247 200 / 0.549, 0.484 / 0.338 / 0.340.)  "
+        "The reference's own protocol through the C++ API "
         f"(`readme_loop`): `draw()` until the device has finished **{loop['draw_complete_ms']['median']:.3f} ms** (p10 {loop['draw_complete_ms']['p10']:.3f} / "
         f"p90 {loop['draw_complete_ms']['p90']:.3f}; submit {loop['draw_submit_ms']['median']:.3f}), `display()` incl. the 8-bit resolve and the 3 MB read-back "
         f"{loop['display_ms']['median']:.3f} ms; the reference publishes 17.06 ms for `draw()` on an i7-12800HX.  `cpu_baseline`: "
