@@ -162,3 +162,34 @@ def test_option_is_per_frameset_and_the_default_stays_exact(orc):
     gpu, _ = c.draw(f)                                                              # the ctx's own draw follows the option: off again
     assert np.array_equal(bits(np.stack(gpu)), bits(np.stack(ref)))
     exact_set.close(), approx_set.close(), c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SRZ_FUZZ_SEEDS", "8"))))
+def test_tolerance_mode_on_random_frames(orc, seed):
+    """the fuzz frames of test_gpu_frameset (random soups, every shader, 0-3 lights placed INSIDE the image, exponents 150 / 8 / 2.5,
+    degenerate normals, uvs beyond [0, 1]) through a frameset in the tolerance mode: z, coverage and counters bit-identical, colours
+    within the stated tolerance; frames the tolerance builds do not cover (no light, BUMP / DISPLACEMENT batches) bit-identical"""
+    import torch
+    import srz
+    from test_gpu_frameset import _random_frame
+    rng = np.random.default_rng(5000 + seed)
+    w, h = [(64, 64), (200, 120), (97, 131), (256, 96), (33, 290), (128, 128), (320, 200), (70, 70)][seed % 8]
+    flags = abi.FUSED_CLEAR | (abi.UNIFIED if seed % 3 == 2 else 0)
+    frames = [_random_frame(rng, w, h, int(rng.integers(1, 400)), flags) for _ in range(int(rng.integers(2, 8)))]
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    ctx.set_option(abi.OPT_APPROX_SHADE, 1)
+    fs = ctx.frameset(frames)
+    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    fs.render(out.data_ptr(), fs.out_bytes, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i, f in enumerate(frames):
+        ref, rst, pre, s_class = oracle_with_probes(orc, f)
+        covered = len(f.lights) >= 1 and all(int(f._batches[b].shader) in (abi.SHADER_NORMAL, abi.SHADER_TEXTURE, abi.SHADER_PHONG) for b in range(f.c.n_batches))
+        if covered:
+            check(tuple(got[i]), rst, ref, rst, pre, s_class, f"fuzz seed {seed} frame {i}")
+        else:
+            for p in range(4):
+                assert np.array_equal(bits(got[i, p]), bits(ref[p])), (seed, i, p)
+    fs.close(), ctx.close()
