@@ -20,7 +20,7 @@ for r in csv.DictReader(open(f)):
     t[k] = float(r["AverageNs"]) / 1e3
 log = open(sys.argv[1] + "/run.log").read()
 m = re.search(r"wall/render=([\d.]+) ms.*total_ms=([\d.]+)", log)
-keys = ["k_setup<false>", "k_chunks", "k_bin", "k_raster<1>", "k_raster_slow<false>", "k_shade<false, 2, false>", "k_shade<false, 0, false>", "k_clear"]
+keys = ["k_setup<false>", "k_chunks", "k_bin", "k_raster<1>", "k_raster_slow<false>", "k_shade<false, 2, false, false>", "k_shade<false, 0, false, false>", "k_clear"]
 print(f"{sys.argv[3]:8s} {sys.argv[2]:18s} " + " ".join(f"{k.split('<')[0][2:]}{'F' if 'true>' in k else ''}={t.get(k, 0):7.1f}" for k in keys if k in t) + (f"  wall={float(m.group(1))*1e3:7.1f} events={float(m.group(2))*1e3:7.1f}" if m else ""))
 PY
   done

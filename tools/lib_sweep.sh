@@ -8,5 +8,5 @@ for lib in "$@"; do
   python3 bench.py --no-cpu-baseline --no-extras $args 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print(round(d['value']), round(d['ms_per_step'],4), round(r['frac'],4), [round(x,3) for x in d['ms_per_step_p10_median_p90']], 'shade', round(r['one_stream']['k_shade_ms'],4))" >> $out || exit 1
+print(round(d['value']), round(d['ms_per_step'],4), round(r['frac'],4), [round(x,3) for x in d['ms_per_step_p10_median_p90']], 'one-stream us [setup+bin, raster, shade]', r['one_stream_us'])" >> $out || exit 1
 done
