@@ -39,7 +39,8 @@ extern "C" {
  *      srz_comm_*, srz_frameset_allgather / _deinterleave / _exchange_bytes, srz_kernel_time_samples
  *   4  srz_frameset_allgather_inplace, srz_frameset_gathered_row_offset, srz_frameset_read_gathered_frame
  *   5  srz_set_option, srz_verify_fastpow; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
- *   6  SRZ_OPT_APPROX_SHADE (the tolerance mode of the shaders); srz_frameset_resolve8 / _deinterleave / the bgr8 exchange take any width
+ *   6  SRZ_OPT_APPROX_SHADE (the tolerance mode of the shaders); srz_frameset_resolve8 / _deinterleave / the bgr8 exchange take any width;
+ *      the tile-list pool is sized by srz_frameset_create / srz_sceneset_create, the first srz_frameset_render no longer blocks
  */
 #define SRZ_ABI_VERSION 6
 
@@ -163,10 +164,9 @@ void srz_destroy(srz_ctx *ctx);
 const char *srz_last_error(const srz_ctx *ctx); /* ctx may be NULL: last error of srz_create */
 
 /* Per-ctx switches (value 0 / 1), applied to framesets created AFTERWARDS:
- *   SRZ_OPT_POOL_LAZY  1 = the first render of a set does NOT size the tile-list pool by its own demand (see srz_frameset_render:
- *                      no host wait in the first render; bands whose lists do not fit take the ordered rasteriser until a later
- *                      render has grown the pool).  Default 0, or 1 when the environment variable SRZ_POOL_LAZY is set — read
- *                      ONCE, in srz_create. */
+ *   SRZ_OPT_POOL_LAZY  1 = creating a set does NOT size its tile-list pool by a binning pass of its own (see srz_frameset_render:
+ *                      bands whose lists do not fit take the ordered rasteriser until a later render has grown the pool).
+ *                      Default 0, or 1 when the environment variable SRZ_POOL_LAZY is set — read ONCE, in srz_create. */
 #define SRZ_OPT_POOL_LAZY 1
 /*   SRZ_OPT_APPROX_SHADE  1 = TOLERANCE MODE of the fragment shaders (default 0 = exact: bit-identical to the CPU oracle).  The
  *                      reference's x86 path shades with approximate instructions — _mm256_rcp_ps (include/shader/Shader.hpp:131,
@@ -212,13 +212,14 @@ int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_f
  * where local_rows = srz_frameset_local_rows() (= height for an unsharded ctx, else
  * bands_per_rank*32, zero-padded).  d_out is a DEVICE pointer (e.g. a torch tensor's data_ptr),
  * stream a hipStream_t (NULL = the ctx's own non-blocking stream; pass SRZ_STREAM_NULL for HIP's null stream:
- * work on the ctx's stream is NOT ordered against the null stream).  The call is asynchronous on that stream — with ONE
- * exception: the FIRST render of a set (per sub-batch of a very large one) waits on the host for the binning kernel's count
- * of (triangle, tile) pairs (a device→host copy + hipStreamSynchronize(stream)), grows the tile-list pool if a band did not
- * fit (hipDeviceSynchronize + hipMalloc) and bins again, so that a one-shot set is rendered by the fast path as a whole.  That
- * first call therefore cannot be captured into a hipGraph and serialises with other streams; every later render of the set
- * is asynchronous (the pool follows the previous renders' demand; growth — rare — is the one place they wait).
- * srz_set_option(ctx, SRZ_OPT_POOL_LAZY, 1) before creating the set switches the blocking first render off. */
+ * work on the ctx's stream is NOT ordered against the null stream).  The call is asynchronous on that stream, the first render of
+ * a set included: srz_frameset_create / srz_sceneset_create (synchronous anyway: they upload) run a binning pass of their own and
+ * size the tile-list pool by its count of (triangle, tile) pairs, so a set is rendered by the fast path as a whole from its first
+ * render on.  Afterwards the pool follows the previous renders'
+ * demand (a sceneset's geometry may change with srz_sceneset_update); growth — rare — is the one place a render waits for the
+ * device (hipDeviceSynchronize + hipMalloc), and the bands that did not fit take the ordered rasteriser in the render that found out.
+ * srz_set_option(ctx, SRZ_OPT_POOL_LAZY, 1) before creating the set skips the creation-time pass (the pool then only follows the
+ * renders' demand). */
 #define SRZ_STREAM_NULL ((void *)(intptr_t)-1)
 int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out);
 /* Same, but the frames are given as meshes + matrices: every srz_frameset_render first runs the vertex stage on the

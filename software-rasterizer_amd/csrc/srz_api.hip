@@ -357,15 +357,19 @@ int collect_events(srz_ctx *ctx) {
 
 // setup → bands → raster for every frame of the set, asynchronously on `s`
 // (one_frame_scratch: a counting run whose pixels nobody reads — every frame writes the SAME one-frame buffer)
-int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or, hipStream_t s, bool stats, bool one_frame_scratch = false) {
+// (size_only: the creation-time pass of srz_frameset_create / srz_sceneset_create — setup + binning of every sub-batch and the sizing
+// of the tile-list pool by their demand, nothing rasterised, no texture needed yet)
+int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or, hipStream_t s, bool stats, bool one_frame_scratch = false,
+                bool size_only = false) {
   if (fs->shard_rank != ctx->shard_rank || fs->shard_world != ctx->shard_world)
     return fail(ctx, SRZ_E_INVALID, "frameset was created under a different shard (call srz_set_shard before srz_frameset_create)");
   for (const BatchDesc &b : fs->h_batches) {
+    if (size_only) break;
     bool needs = b.shader == SRZ_SHADER_TEXTURE || b.shader == SRZ_SHADER_DISPLACEMENT || b.shader == SRZ_SHADER_BUMP;
     if (needs && (b.tex_id < 0 || b.tex_id >= MAX_TEX || !ctx->h_tex[b.tex_id].bgrx))
       return fail(ctx, SRZ_E_TEXTURE, "batch uses texture slot " + std::to_string(b.tex_id) + " which was never uploaded");
   }
-  if (fs->sdesc_version != ctx->tex_version && !fs->h_batches.empty()) { // (re)resolve batch → shader/texture
+  if (!size_only && fs->sdesc_version != ctx->tex_version && !fs->h_batches.empty()) { // (re)resolve batch → shader/texture
     std::vector<ShadeDescG> &h = fs->h_sdesc; // (owned by the set: the asynchronous copy below may read it after we return)
     h.resize(fs->h_batches.size());
     for (size_t i = 0; i < h.size(); ++i) {
@@ -405,7 +409,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
                    std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_ORDERED_RASTER) != 0; }))
                       ? 1u : 0u;
   EventPair ep{};
-  const bool timed = ctx->timing != 0 && !stats && ctx->ev_used.size() < 65536, detailed = timed && ctx->timing >= 2;
+  const bool timed = ctx->timing != 0 && !stats && !size_only && ctx->ev_used.size() < 65536, detailed = timed && ctx->timing >= 2;
   if (timed) {
     int rc = get_events(ctx, ep);
     if (rc) return rc;
@@ -418,7 +422,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     HIP_TRY(ctx, hipMemsetAsync(fs->d_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * fs->pool_n_sub, s));
     HIP_TRY(ctx, hipMemsetAsync(fs->d_slow_count, 0, 2 * sizeof(uint32_t), s));
   }
-  const bool turns = !stats && fs->max_tiles >= 8192 && !ctx->env_no_turns; // (batches; small jobs are launch-bound and gain nothing)
+  const bool turns = !stats && !size_only && fs->max_tiles >= 8192 && !ctx->env_no_turns; // (batches; small jobs are launch-bound and gain nothing)
   if (turns) {
     if (!ctx->ev_raster[0])
       for (int i = 0; i < srz_ctx::EV_RING; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_raster[i], hipEventDisableTiming));
@@ -434,7 +438,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // fused clear of the tiles no bbox reaches: beside k_raster on a second stream (batches), or in the rasteriser (small jobs)
   const bool any_fused = (flags_or & SRZ_FUSED_CLEAR) != 0 ||
                          std::any_of(fs->h_frames.begin(), fs->h_frames.end(), [](const FrameDesc &f) { return (f.flags & SRZ_FUSED_CLEAR) != 0; });
-  const bool side = any_fused && fs->max_tiles >= 8192;
+  const bool side = any_fused && fs->max_tiles >= 8192 && !size_only;
   if (side && !ctx->stream2) {
     // The clear must run BESIDE the launch stream, so it may not share a hardware queue with it: HIP deals its streams
     // round-robin onto a few hardware queues (seen: the caller's stream and this one on the same queue — the clear then ran
@@ -517,6 +521,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
         launch_bin(v, n, fs->max_tris, s);
       }
     }
+    if (size_only) continue; // (the creation-time pass ends with the binning)
     if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
     unsigned ev = 0;
     if (side) {
@@ -842,8 +847,24 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   return SRZ_OK;
 }
 
+// A set made through the public entry points sizes its tile-list pool NOW (creation is synchronous anyway: it uploads), by a binning
+// pass of its own, so that every srz_frameset_render — the first included — is asynchronous on its stream.  (The ctx's internal
+// one-frame sets of srz_draw / srz_draw_scene are rendered at once: their first render does the sizing.)
+static int size_pool_at_create(srz_ctx *ctx, srz_frameset **out) {
+  srz_frameset *fs = *out;
+  if (fs->pool_sized) return SRZ_OK; // SRZ_OPT_POOL_LAZY
+  int rc = render_impl(ctx, fs, nullptr, 0, ctx->stream, false, false, /*size_only=*/true);
+  if (rc == SRZ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, SRZ_E_NODEVICE, "srz_frameset_create: the binning pass failed");
+  if (rc != SRZ_OK) {
+    srz_frameset_destroy(ctx, fs);
+    *out = nullptr;
+  }
+  return rc;
+}
+
 int srz_frameset_create(srz_ctx *ctx, const srz_frame *frames, int n_frames, srz_frameset **out) {
-  return build_frameset(ctx, frames, n_frames, out, true);
+  int rc = build_frameset(ctx, frames, n_frames, out, true);
+  return rc == SRZ_OK ? size_pool_at_create(ctx, out) : rc;
 }
 
 int srz_mesh_upload(srz_ctx *ctx, int mesh_id, const srz_vertex *verts, uint32_t n_verts, const uint32_t *faces, uint32_t n_faces) {
@@ -944,7 +965,7 @@ int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frame
   fs->d_lights = reinterpret_cast<srz_light *>(blk + fs->dyn_lights_off);
   fs->d_draws = reinterpret_cast<DrawDesc *>(blk + fs->dyn_draws_off);
   *out = fs;
-  return SRZ_OK;
+  return size_pool_at_create(ctx, out); // (with the matrices of creation: a later srz_sceneset_update is followed by the lazy growth)
 }
 
 int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *frames, int n_frames) {

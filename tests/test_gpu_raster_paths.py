@@ -138,6 +138,39 @@ def test_pool_overflow_then_growth(ctx, orc, monkeypatch):
         ctx.set_option(99, 1)
 
 
+def test_pool_is_sized_when_the_set_is_created(orc):
+    """the same screen-filling triangles WITHOUT the lazy option: srz_frameset_create runs a binning pass of its own and sizes the
+    pool, so the very first render (asynchronous like every other) is the fast path's and equals the oracle; a second context
+    proves it for a sharded set too"""
+    import srz
+    w = h = 1024
+    n = 24
+    t = np.zeros(n, abi.TRI_DTYPE)
+    rng = np.random.default_rng(6)
+    for i in range(n):
+        t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
+    nn = rng.normal(size=(n, 3, 3))
+    t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
+    f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
+    rc, ref, _ = orc.draw(f)
+    assert rc == 0
+    for (rank, world) in ((0, 1), (1, 2)):
+        c = srz.Context(0, rank, world)
+        fs = c.frameset([f, f])
+        out = torch.full(fs.out_shape, -1.0, dtype=torch.float32, device="cuda")
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        if world == 1:
+            same(got[0], ref, "sized at creation, first render")
+            same(got[1], ref, "sized at creation, first render, frame 1")
+        else:
+            from srz import parallel
+            for (lb, b, r0, r1) in parallel.band_rows(h, rank, world):
+                assert np.array_equal(got[0][:, lb * 32: lb * 32 + (r1 - r0)].view(np.uint32), np.stack(ref)[:, r0:r1].view(np.uint32)), (rank, b)
+        fs.close(), c.close()
+
+
 def test_many_small_frames_fill_every_subpool(ctx, orc):
     """enough frames that the pool is split into several sub-pools; every frame must still come out right"""
     frames = [scenes.config2(i, size=256) for i in range(40)]
