@@ -182,7 +182,7 @@ struct Decoder {
         if (have_sof) fail("two frame headers");
         if (n < 6 || s[0] != 8) fail("only 8-bit samples");
         H = s[1] << 8 | s[2], W = s[3] << 8 | s[4], ncomp = s[5];
-        if (W <= 0 || H <= 0 || W > 32768 || H > 32768) fail("bad size");
+        if (W <= 0 || H <= 0 || W > 32768 || H > 32768 || (size_t)W * (size_t)H > ((size_t)1 << 28)) fail("bad size"); // (bounds the allocations below)
         if ((ncomp != 1 && ncomp != 3) || n < 6 + 3 * (size_t)ncomp) fail("only 1 or 3 components");
         for (int c = 0; c < ncomp; ++c) {
           comp[c].id = s[6 + 3 * c], comp[c].h = s[7 + 3 * c] >> 4, comp[c].v = s[7 + 3 * c] & 15, comp[c].tq = s[8 + 3 * c] & 3;
