@@ -35,11 +35,12 @@ struct Huff {
   // canonical decoding (T.81 Annex F.2.2.3): per code length the largest code, the first code's index
   int32_t maxcode[18], valptr[17], mincode[17];
   uint8_t look_len[512], look_val[512]; // 9-bit look-ahead: code length (0 = longer) and symbol
-  void build() {
+  bool build() { // false: more codes of some length than a prefix code has room for (a corrupt table)
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k, mincode[l] = code;
       code += bits[l], k += bits[l];
+      if (code > (1 << l)) return false;
       maxcode[l] = bits[l] ? code - 1 : -1;
       code <<= 1;
     }
@@ -51,6 +52,7 @@ struct Huff {
         for (int f = 0; f < (1 << (9 - l)); ++f) look_len[(code << (9 - l)) | f] = (uint8_t)l, look_val[(code << (9 - l)) | f] = vals[k];
       code <<= 1;
     }
+    return true;
   }
 };
 
@@ -176,7 +178,7 @@ struct Decoder {
           std::memcpy(h.vals, s + i, cnt);
           i += cnt;
           h.defined = true;
-          h.build();
+          if (!h.build()) fail("bad DHT");
         }
       } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) { // SOF0 / 1 / 2
         if (have_sof) fail("two frame headers");
@@ -288,8 +290,8 @@ struct Decoder {
   void block_sequential(Bits &b, Comp &k, int16_t *blk) {
     const Huff &dc = hdc[k.dc_tbl], &ac = hac[k.ac_tbl];
     if (!dc.defined || !ac.defined) fail("scan uses an undefined Huffman table");
-    const int t = decode_sym(b, dc);
-    const int diff = t ? extend(b.get(t & 15), t & 15) : 0;
+    const int t = decode_sym(b, dc) & 15; // (a category above 11 only comes out of a corrupt table)
+    const int diff = t ? extend(b.get(t), t) : 0;
     k.dc_pred += diff;
     blk[0] = (int16_t)k.dc_pred;
     for (int i = 1; i < 64;) {
