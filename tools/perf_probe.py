@@ -30,6 +30,8 @@ frames = [uniq[i % len(uniq)] for i in range(F)]
 print(f"built {len(uniq)} frames in {time.time()-t0:.1f}s; tris/frame={frames[0].n_tris}")
 ctx = srz.Context(0)
 ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+if os.environ.get('PROBE_APPROX'):  # the tolerance mode of the shaders (SRZ_OPT_APPROX_SHADE)
+    ctx.set_option(abi.OPT_APPROX_SHADE, 1)
 fs = ctx.frameset(frames)
 st = fs.stats()
 print("stats", st)
