@@ -182,9 +182,18 @@ void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &
 // 0 <= p <= 256 takes the builds with the exact multiplication chains, a non-integer exponent in (0, 4096] the builds whose power
 // is pow_fast (FD_GENPOW; not combined with BUMP / DISPLACEMENT batches), every other exponent the generic build.  Sets FD_FAST_SHADE + the
 // light count in the host copies of the descriptors.
-void classify_frames(srz_frameset *fs) {
+// (lights: the host copy of the set's lights, indexed by FrameDesc::light_off — or, `one_frame`, that one frame's own array)
+void classify_frames(srz_frameset *fs, const srz_light *lights, bool one_frame = false) {
   fs->fast_mask = 0, fs->any_generic = false;
   for (FrameDesc &d : fs->h_frames) {
+    // FD_GREY: three bit-equal channels in ka, ks and every light's intensity (the shaders then compute a PHONG pixel's channel once)
+    bool grey = lights != nullptr || d.n_lights == 0;
+    grey = grey && std::memcmp(&d.ka[0], &d.ka[1], 4) == 0 && std::memcmp(&d.ka[1], &d.ka[2], 4) == 0 &&
+           std::memcmp(&d.ks[0], &d.ks[1], 4) == 0 && std::memcmp(&d.ks[1], &d.ks[2], 4) == 0;
+    for (uint32_t l = 0; grey && l < d.n_lights; ++l) {
+      const srz_light &L = lights[(one_frame ? 0u : d.light_off) + l];
+      grey = std::memcmp(&L.intensity[0], &L.intensity[1], 4) == 0 && std::memcmp(&L.intensity[1], &L.intensity[2], 4) == 0;
+    }
     const bool intpow = d.p >= 0.0f && d.p <= 256.0f && d.p == std::trunc(d.p);
     bool bumpy = false;
     for (uint32_t b = 0; b < d.n_batches; ++b) {
@@ -197,7 +206,7 @@ void classify_frames(srz_frameset *fs) {
     const bool approx = fs->approx_shade && d.n_lights >= 1u && d.n_lights <= 4u && !bumpy && d.p >= 0.0f && std::isfinite(d.p);
     const bool fast = approx || (!fs->approx_shade && d.n_lights >= 1u && d.n_lights <= 4u && (intpow || (fracpow && !bumpy)));
     const bool plain = approx || intpow;
-    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | FD_PACKED | (7u << FD_NL_SHIFT))) |
+    d.flags = (d.flags & ~(FD_FAST_SHADE | FD_BUMPY | FD_GENPOW | FD_PACKED | FD_GREY | (7u << FD_NL_SHIFT))) | (grey ? FD_GREY : 0u) |
               (fast ? (FD_FAST_SHADE | (d.n_lights << FD_NL_SHIFT) | (bumpy ? FD_BUMPY : 0u) | (plain ? 0u : FD_GENPOW)) : 0u) |
               ((d.n_tris < PACK_IDX_MASK && d.n_batches <= PACK_MAX_BATCHES && !fs->no_packed) ? FD_PACKED : 0u);
     if (fast)
@@ -765,7 +774,6 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
   fs->no_packed = ctx->env_no_packed;
   fs->approx_shade = ctx->opt_approx_shade;
   fs->pool_sized = ctx->opt_pool_lazy; // (SRZ_OPT_POOL_LAZY: no first-render sizing — the pool only follows the previous renders' demand)
-  classify_frames(fs);
 
   // stage host copies (pinned not needed: one-time upload)
   fs->tris_aos = tris_aos && copy_tris;
@@ -789,6 +797,7 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     }
     if (fr.n_lights) std::memcpy(&h_lights[d.light_off], fr.lights, sizeof(srz_light) * fr.n_lights);
   }
+  classify_frames(fs, h_lights.data());
   auto dev_alloc = [&](void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 256)); };
   hipError_t e = hipSuccess;
 #define FS_TRY(expr)                                                                                                   \
@@ -998,7 +1007,7 @@ int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *f
       if (b.shader != dr.shader || b.tex_id != dr.tex_id) b.shader = dr.shader, b.tex_id = dr.tex_id, batches_changed = true;
     }
   }
-  classify_frames(fs);
+  classify_frames(fs, h_lights.data());
   if (ensure_worklists(fs) != hipSuccess) return fail(ctx, SRZ_E_NOMEM, "srz_sceneset_update: hipMalloc of the work lists failed");
   // one asynchronous copy on the context's stream: ordered after every render already submitted there (which may still
   // be reading the descriptors) and before the next one.  Renders submitted on OTHER streams are the caller's to order.
@@ -1479,7 +1488,8 @@ static int refresh_plain_frame(srz_ctx *ctx, srz_frameset *fs, const srz_frame &
   std::memcpy(d.eye, fr.eye, sizeof d.eye), std::memcpy(d.ka, fr.ka, sizeof d.ka), std::memcpy(d.ks, fr.ks, sizeof d.ks);
   d.p = fr.p, d.kh = fr.kh, d.kn = fr.kn;
   d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER);
-  classify_frames(fs);
+  if (fr.n_lights != d.n_lights || (fr.n_lights && !fr.lights)) return fail(ctx, SRZ_E_INVALID, "srz_draw: light count changed");
+  classify_frames(fs, fr.lights, /*one_frame=*/true);
   if (ensure_worklists(fs) != hipSuccess) return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc of the work lists failed");
   HIP_TRY(ctx, hipMemcpyAsync(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   if (fr.n_lights) HIP_TRY(ctx, hipMemcpyAsync(fs->d_lights, fr.lights, sizeof(srz_light) * fr.n_lights, hipMemcpyHostToDevice, s));

@@ -28,6 +28,7 @@ constexpr uint32_t FD_PACKED = 0x4000u;                  // fewer than 2^22 - 1 
                                                          // triangle index | batch << 22 (k_shade stages the tile's triangles without
                                                          // a gather of their batch ids), and the depth keys' tie-breaks carry list positions
 constexpr uint32_t PACK_IDX_BITS = 22, PACK_IDX_MASK = (1u << PACK_IDX_BITS) - 1u, PACK_MAX_BATCHES = 1024;
+constexpr uint32_t FD_GREY = 0x8000u;                    // ka, ks and every light's intensity have three bit-equal channels (FrameK::grey in srz_kernels.hip)
 constexpr uint32_t FD_GENPOW = 0x2000u;                  // a non-integer exponent in (0, 4096]: FAST builds whose power is pow_fast (exp2(p log2 x) in binary64 with a rounding-safety flag)
 constexpr uint32_t SHADE_KIND_GENERIC = 12;              // k_shade builds: kinds 0..3 = FAST for 1..4 lights, 4..7 = the same + BUMPY,
                                                          // 8..11 = FAST for 1..4 lights with any exponent (GENPOW), 12 = generic

@@ -136,6 +136,7 @@ struct IeeeMath {
   __device__ __forceinline__ void div3(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2) {
     q0 = a0 / b, q1 = a1 / b, q2 = a2 / b;
   }
+  __device__ __forceinline__ float div1(float a, float b) { return a / b; } // (div3 for three equal numerators: FrameK::grey)
   __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
   __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
@@ -157,6 +158,10 @@ struct FastMath {
     bad |= ((int)div_den_ok(b) & (int)div_num_ok(a0) & (int)div_num_ok(a1) & (int)div_num_ok(a2)) == 0;
     const float y = rcp_core(b);
     q0 = div_by_rcp(a0, b, y), q1 = div_by_rcp(a1, b, y), q2 = div_by_rcp(a2, b, y);
+  }
+  __device__ __forceinline__ float div1(float a, float b) { // (div3 for three equal numerators: the same check, the same quotient)
+    bad |= ((int)div_den_ok(b) & (int)div_num_ok(a)) == 0;
+    return div_by_rcp(a, b, rcp_core(b));
   }
   __device__ __forceinline__ float rcp(float x) {
     track(f2u_(x) & 0x7fffffffu);
@@ -186,6 +191,7 @@ struct ApproxMath {
     const float y = __builtin_amdgcn_rcpf(b);
     q0 = a0 * y, q1 = a1 * y, q2 = a2 * y;
   }
+  __device__ __forceinline__ float div1(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
   // (the one reciprocal of the coverage arithmetic, tri_consts: EXACT — the barycentrics, hence depth, normals' and texture
   // coordinates' interpolation, are the oracle's bits in this mode too: a texture coordinate one ulp off can round to the
   // neighbouring texel, which no colour tolerance covers)
@@ -933,6 +939,11 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
 struct FrameK { // per-frame constants, wave-uniform (live in SGPRs)
   float eye[3], ka[3], ks[3], p, kh, kn;
   uint32_t n_lights;
+  // FD_GREY (decided on the host): ka, ks and every light's intensity have three bit-equal channels.  The three channels of a
+  // Blinn-Phong sum then differ only through the surface colour kd: with kd = (1, 1, 1) — the PHONG shader — they are the SAME
+  // operations on the SAME operands, so the FAST builds compute one channel and copy it (identical bits by construction), and the
+  // scalar path divides the intensity by the distance once instead of three times for every shader
+  bool grey;
   const SRZ_CAS srz_light *lights;
 };
 struct ShadeDesc { // what a batch's Shader object holds: type + texture (Shader::texture, width_256/height_256)
@@ -1022,6 +1033,15 @@ __device__ __forceinline__ void v_shade(M &m, const FrameK &K, const ShadeDesc &
       for (int l = 0; l < NLC; ++l) v_blinn_phong_terms<M, NL>(m, nx, ny, nz, K, K.lights + l, px, py, pz, t[l]);
       asm volatile("" : "+v"(t[0].cosT), "+v"(t[NLC - 1].cosT), "+v"(texel)); // (keeps the decode below the terms)
       decode();
+      if (SH == SRZ_SHADER_PHONG && K.grey) { // (wave-uniform) kd = 1 and grey constants: channel 0's operations ARE the other two's
+#pragma unroll
+        for (int l = 0; l < NLC; ++l) {
+          const float I0 = (K.lights + l)->intensity[0];
+          c0 = c0 + 1.0f * fmaf_(K.ka[0], I0, fmaf_(t[l].d0 * 1.0f, t[l].cosA, (t[l].d0 * K.ks[0]) * t[l].cosT));
+        }
+        r0 = r1 = r2 = sse_min(sse_max(c0, 0.0f), 1.0f) * 255.0f;
+        return;
+      }
 #pragma unroll
       for (int l = 0; l < NLC; ++l) { // (summed in the lights' order, like the loop below)
         float o0, o1, o2;
@@ -1089,7 +1109,10 @@ __device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float
   normalize3(m, nx, ny, nz);
   float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
   float dsq = m.len2d(ldx, ldy); // (binary64 in the reference: std::pow(x, 2), std::sqrt)
-  m.div3(I0, I1, I2, dsq, t.d0, t.d1, t.d2);
+  if (K.grey) // (wave-uniform: I0 == I1 == I2 bit for bit, so the three quotients are one)
+    t.d0 = t.d1 = t.d2 = m.div1(I0, dsq);
+  else
+    m.div3(I0, I1, I2, dsq, t.d0, t.d1, t.d2);
   float nlx = ldx, nly = ldy, nlz = ldz;
   normalize3(m, nlx, nly, nlz);
   t.cosA = std_max(0.0f, dot3(nx, ny, nz, nlx, nly, nlz));
@@ -1164,6 +1187,16 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
       if (SH == SRZ_SHADER_TEXTURE) {
         kd0 = m.div255((float)(texel & 0xffu)), kd1 = m.div255((float)((texel >> 8) & 0xffu)), kd2 = m.div255((float)((texel >> 16) & 0xffu));
         if (!inside) kd0 = kd1 = kd2 = 0.0f;
+      }
+      if (SH == SRZ_SHADER_PHONG && K.grey) { // (wave-uniform) kd = 1 and grey constants: one channel, copied (see FrameK::grey)
+#pragma unroll
+        for (int l = 0; l < NLC; ++l) {
+          const float I0 = (K.lights + l)->intensity[0];
+          c0 = c0 + ((K.ka[0] * I0 + (t[l].cosA * 1.0f) * t[l].d0) + (t[l].cosT * K.ks[0]) * t[l].d0) * 1.0f;
+        }
+        const float q = std_clamp(c0, 0.0f, 1.0f) * 255.0f;
+        r0 = r1 = r2 = (q == q) ? (float)(uint32_t)q : 0.0f;
+        return;
       }
 #pragma unroll
       for (int l = 0; l < NLC; ++l) {
@@ -1349,6 +1382,11 @@ __global__ void probe_v(RenderArgs a, float *o) {
   K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
   K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
   K.p = 150.0f, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = 2; // constants: the static count is the dynamic path
+#ifdef SRZ_PROBE_GREY
+  K.grey = true;
+#else
+  K.grey = false;
+#endif
   K.lights = as_const(a.lights);
   TriFetch tf;
   fetch_tri(as_const(a.tris), as_const(a.tri_batch), threadIdx.x, tf);
@@ -2334,6 +2372,7 @@ void k_shade(RenderArgs a) {
       K.ka[0] = fd->ka[0], K.ka[1] = fd->ka[1], K.ka[2] = fd->ka[2];
       K.ks[0] = fd->ks[0], K.ks[1] = fd->ks[1], K.ks[2] = fd->ks[2];
       K.p = fd->p, K.kh = fd->kh, K.kn = fd->kn, K.n_lights = fd->n_lights;
+      K.grey = (fd->flags & FD_GREY) != 0u;
       K.lights = as_const(ap->lights) + fd->light_off;
       // chunk c of the tile, dealt round-robin to the waves: the S chunks first (the dearer ones: ~450 instructions against ~310), so that
       // the waves' loads differ by at most one V chunk at the barrier behind the passes

@@ -4,11 +4,11 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/gpurun_out/isa
-SH=${1:--1}   # (a second argument: the tolerance mode's ApproxMath instead of FastMath)
+SH=${1:--1}   # (second argument `approx`: the tolerance mode's ApproxMath instead of FastMath; third argument `grey`: FrameK::grey set)
 # -1: generic per-pixel build; 0 NORMAL / 1 TEXTURE / 2 PHONG: the FAST variant (2 lights, p = 150)
 for v in V S; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DSRZ_ISA_PROBE -DSRZ_PROBE_SH=$SH \
-    $([ $v = S ] && echo -DSRZ_PROBE_S) $([ -n "$2" ] && echo -DSRZ_PROBE_APPROX) -I$R/include --cuda-device-only -S $R/software-rasterizer_amd/csrc/srz_kernels.hip \
+    $([ $v = S ] && echo -DSRZ_PROBE_S) $([ "$2" = approx ] && echo -DSRZ_PROBE_APPROX) $([ "$3" = grey ] && echo -DSRZ_PROBE_GREY) -I$R/include --cuda-device-only -S $R/software-rasterizer_amd/csrc/srz_kernels.hip \
     -o $R/gpurun_out/isa/probe_$v.s
 done
 python3 - <<PY
