@@ -136,7 +136,6 @@ struct IeeeMath {
   __device__ __forceinline__ void div3(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2) {
     q0 = a0 / b, q1 = a1 / b, q2 = a2 / b;
   }
-  __device__ __forceinline__ float div1(float a, float b) { return a / b; } // (div3 for three equal numerators: FrameK::grey)
   __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
   __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
   __device__ __forceinline__ float rsqrt2(float d) { return 1.0f / __builtin_sqrtf(d); }
@@ -158,10 +157,6 @@ struct FastMath {
     bad |= ((int)div_den_ok(b) & (int)div_num_ok(a0) & (int)div_num_ok(a1) & (int)div_num_ok(a2)) == 0;
     const float y = rcp_core(b);
     q0 = div_by_rcp(a0, b, y), q1 = div_by_rcp(a1, b, y), q2 = div_by_rcp(a2, b, y);
-  }
-  __device__ __forceinline__ float div1(float a, float b) { // (div3 for three equal numerators: the same check, the same quotient)
-    bad |= ((int)div_den_ok(b) & (int)div_num_ok(a)) == 0;
-    return div_by_rcp(a, b, rcp_core(b));
   }
   __device__ __forceinline__ float rcp(float x) {
     track(f2u_(x) & 0x7fffffffu);
@@ -191,7 +186,6 @@ struct ApproxMath {
     const float y = __builtin_amdgcn_rcpf(b);
     q0 = a0 * y, q1 = a1 * y, q2 = a2 * y;
   }
-  __device__ __forceinline__ float div1(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
   // (the one reciprocal of the coverage arithmetic, tri_consts: EXACT — the barycentrics, hence depth, normals' and texture
   // coordinates' interpolation, are the oracle's bits in this mode too: a texture coordinate one ulp off can round to the
   // neighbouring texel, which no colour tolerance covers)
@@ -941,8 +935,9 @@ struct FrameK { // per-frame constants, wave-uniform (live in SGPRs)
   uint32_t n_lights;
   // FD_GREY (decided on the host): ka, ks and every light's intensity have three bit-equal channels.  The three channels of a
   // Blinn-Phong sum then differ only through the surface colour kd: with kd = (1, 1, 1) — the PHONG shader — they are the SAME
-  // operations on the SAME operands, so the FAST builds compute one channel and copy it (identical bits by construction), and the
-  // scalar path divides the intensity by the distance once instead of three times for every shader
+  // operations on the SAME operands, so the FAST builds compute one channel and copy it (identical bits by construction).  Only
+  // BEHIND a pixel's light terms: a branch inside them (one division instead of three in the scalar path) cost the TEXTURE builds
+  // 1.5 % — the terms are kept one straight line so that their independent normalisations interleave
   bool grey;
   const SRZ_CAS srz_light *lights;
 };
@@ -1109,10 +1104,7 @@ __device__ __forceinline__ void s_blinn_phong_terms(M &m, const FrameK &K, float
   normalize3(m, nx, ny, nz);
   float ldx = Lx - px, ldy = Ly - py, ldz = Lz - pz;
   float dsq = m.len2d(ldx, ldy); // (binary64 in the reference: std::pow(x, 2), std::sqrt)
-  if (K.grey) // (wave-uniform: I0 == I1 == I2 bit for bit, so the three quotients are one)
-    t.d0 = t.d1 = t.d2 = m.div1(I0, dsq);
-  else
-    m.div3(I0, I1, I2, dsq, t.d0, t.d1, t.d2);
+  m.div3(I0, I1, I2, dsq, t.d0, t.d1, t.d2); // (no branch on FrameK::grey here: the terms of a pixel stay one straight line of code)
   float nlx = ldx, nly = ldy, nlz = ldz;
   normalize3(m, nlx, nly, nlz);
   t.cosA = std_max(0.0f, dot3(nx, ny, nz, nlx, nly, nlz));

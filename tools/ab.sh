@@ -21,7 +21,8 @@ for r in csv.DictReader(open(f)):
 log = open(sys.argv[1] + "/run.log").read()
 m = re.search(r"wall/render=([\d.]+) ms.*total_ms=([\d.]+)", log)
 keys = ["k_setup<false>", "k_chunks", "k_bin", "k_raster<1>", "k_raster_slow<false>", "k_shade<false, 2, false, false>", "k_shade<false, 0, false, false>", "k_clear"]
-print(f"{sys.argv[3]:8s} {sys.argv[2]:18s} " + " ".join(f"{k.split('<')[0][2:]}{'F' if 'true>' in k else ''}={t.get(k, 0):7.1f}" for k in keys if k in t) + (f"  wall={float(m.group(1))*1e3:7.1f} events={float(m.group(2))*1e3:7.1f}" if m else ""))
+shade_fast = sum(v for k, v in t.items() if k.startswith("k_shade<false,") and not k.startswith("k_shade<false, 0,"))
+print(f"{sys.argv[3]:8s} {sys.argv[2]:18s} " + " ".join(f"{k.split('<')[0][2:]}{'F' if 'true>' in k else ''}={t.get(k, 0):7.1f}" for k in keys if k in t and "k_shade" not in k) + f" shade_fast={shade_fast:7.1f}" + (f"  wall={float(m.group(1))*1e3:7.1f} events={float(m.group(2))*1e3:7.1f}" if m else ""))
 PY
   done
 done
