@@ -282,3 +282,129 @@ def test_omp_and_row_band_draws_equal_the_serial_draw(orc):
     assert rc == 0 and n >= 1
     for a, b in zip(pl, ref):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- closed forms from the source, in numpy binary64
+def _bary(P, A, B, C):
+    """alpha, beta, gamma of the pixel corner P as src/Rasterizer.cpp:53-70 / :89-127 define them: areas of (P,B,C) and (P,C,A) over (A,B,C)"""
+    cr = lambda u, v: u[0] * v[1] - u[1] * v[0]  # noqa: E731
+    area = cr(B - A, C - A)
+    al, be = cr(B - P, C - P) / area, cr(C - P, A - P) / area
+    return al, be, 1.0 - al - be
+
+
+def _blinn_phong64(P, n, kd, eye, lights, ka=0.005, ks=0.7937, p=150.0):
+    """Shader::BlinnPhong (src/Shader.cpp:510-543) summed over the lights, per channel, before the clamp"""
+    n = n / np.linalg.norm(n)
+    out = np.zeros(3)
+    for Lp, I in lights:
+        Lp, I = np.asarray(Lp, float), np.asarray(I, float)
+        l = Lp - P
+        d = I / np.sqrt((Lp[0] - P[0]) ** 2 + (Lp[1] - P[1]) ** 2)          # "distanceSquared" is a 2-D distance (quirk 7)
+        cos_t = max(0.0, n @ (l / np.linalg.norm(l)))
+        h = l + (np.asarray(eye, float) - P)
+        cos_a = max(0.0, n @ (h / np.linalg.norm(h)))
+        out += (ka * I + cos_t * kd * d + cos_a ** p * ks * d) * kd
+    return out
+
+
+def test_phong_known_value_scalar_tail_class(orc):
+    """a pixel of the scalar-tail columns, two coloured lights, a slanted normal: Shader::BlinnPhong in closed form, clamped, times 255,
+    truncated (Tools::normalizedToRGB, src/Tools.cpp:94-104)"""
+    A, B, C = np.array([8.0, 8.0]), np.array([8.0, 28.5]), np.array([28.5, 8.0])   # the record's vertex order (tri = ccw with b, c swapped)
+    t = tri(tuple(A), tuple(B), tuple(C), z=(40.0, 55.0, 70.0))
+    t["nrm"][0] = [[0.2, -0.3, 0.9]] * 3
+    lights = [((40.0, 3.0, 90.0), (6.0, 9.0, 12.0)), ((5.0, 30.0, 20.0), (3.0, 2.0, 1.0))]
+    eye = (0.0, 0.0, 1.0)
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_PHONG, lights=lights, eye=eye))
+    assert rc == 0
+    for (x, y) in ((25, 9), (26, 9), (24, 11)):                       # bbox x 8..28: columns 24..28 are the scalar tail
+        P2 = np.array([float(x), float(y)])
+        al, be, ga = _bary(P2, A, B, C)
+        assert min(al, be, ga) > 0
+        z = al * 40.0 + be * 55.0 + ga * 70.0
+        assert abs(pl[0][y, x] - z) < 1e-4
+        c = _blinn_phong64(np.array([x, y, z], float), np.array([0.2, -0.3, 0.9]), np.ones(3), eye, lights)
+        want = np.floor(np.clip(c, 0.0, 1.0) * 255.0)
+        got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
+        assert (got == np.floor(got)).all() and np.abs(got - want).max() <= 1.0, (x, y, got, want, np.clip(c, 0, 1) * 255)
+        assert 5.0 < got.min() and got.max() < 250.0 and len(set(got.tolist())) == 3   # a meaningful, unsaturated, coloured value
+
+
+def test_interpolated_normals_and_texture_coordinates_in_both_classes(orc):
+    """per-vertex normals and uv: NORMAL shader = the interpolated, normalised normal as a colour (V: float, S: truncated);
+    TEXTURE shader: the texel the interpolated uv selects (V: round half even of u*w clamped to w-1, include/loader/TextureLoader.hpp:26-74;
+    S: truncation of clamp(u)*w, src/TextureLoader.cpp:14-31) — the texel's id is read back through an ambient-only light"""
+    A, B, C = np.array([8.0, 8.0]), np.array([8.0, 28.5]), np.array([28.5, 8.0])   # the record's vertex order
+    nrm = np.array([[0.0, 0.0, -1.0], [0.6, 0.0, -0.8], [0.0, 0.8, -0.6]])
+    uv = np.array([[0.05, 0.10], [0.95, 0.15], [0.10, 0.90]])
+    t = tri(tuple(A), tuple(B), tuple(C))
+    t["nrm"][0], t["uv"][0] = nrm, uv
+    rc, pl, _ = orc.draw(frame(t))
+    assert rc == 0
+    for (x, y, s_class) in ((12, 9, False), (20, 12, False), (25, 9, True), (24, 11, True)):
+        al, be, ga = _bary(np.array([float(x), float(y)]), A, B, C)
+        n = al * nrm[0] + be * nrm[1] + ga * nrm[2]
+        n = n / np.linalg.norm(n)
+        want = (n + 1.0) / 2.0 * 255.0
+        got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
+        if s_class:
+            assert (got == np.floor(got)).all() and np.abs(got - np.floor(want)).max() <= 1.0, (x, y, got, want)
+        else:
+            assert np.abs(got - want).max() < 2e-3, (x, y, got, want)
+    # texel ids: an 8 x 8 texture whose blue channel is 4 * (row * 8 + col); with intensity I and ka the colour is kd * ka * I * 255
+    tex = np.zeros((8, 8, 3), np.uint8)
+    tex[:, :, 0] = (np.arange(64).reshape(8, 8) * 4).astype(np.uint8)
+    orc.texture_set(7, tex)
+    far = [((1e6, 1e6, 1e6), (40.0, 40.0, 40.0))]      # a light so far away that only the ambient term ka * I is left (d ~ 1e-5)
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_TEXTURE, tex=7, lights=far))
+    assert rc == 0
+    for (x, y, s_class) in ((12, 9, False), (20, 12, False), (25, 9, True), (24, 11, True)):
+        al, be, ga = _bary(np.array([float(x), float(y)]), A, B, C)
+        u, v = al * uv[0] + be * uv[1] + ga * uv[2]
+        if s_class:
+            col, row = int(min(max(u, 0.0), 1.0) * 8), int(min(max(v, 0.0), 1.0) * 8)
+        else:
+            col, row = int(np.rint(min(max(u * 8, 0.0), 7.0))), int(np.rint(min(max(v * 8, 0.0), 7.0)))
+        kd = tex[row, col, 0] / 255.0
+        want = (0.005 * 40.0) * kd * 255.0            # Shader::BlinnPhong returns (La + Ld + Ls) * colour with La = ka * I (no kd inside)
+        got = pl[1][y, x]
+        assert abs(got - (np.floor(want) if s_class else want)) <= (1.0 if s_class else 0.05), (x, y, s_class, row, col, got, want)
+
+
+def test_bump_scalar_tail_known_value(orc):
+    """calcBumpMapping + BlinnPhong in closed form for a scalar-tail pixel (src/Shader.cpp:477-507, 624-640): the perturbed normal
+    TBN * (-dU, -dV, 1) from the lengths of three texel colours, then the Blinn-Phong sum with kd = the texel"""
+    A, B, C = np.array([8.0, 8.0]), np.array([8.0, 28.5]), np.array([28.5, 8.0])
+    rng = np.random.default_rng(11)
+    tex = rng.integers(40, 216, (8, 8, 3)).astype(np.uint8)
+    orc.texture_set(8, tex)
+    nvec = np.array([0.3, 0.5, -0.81])
+    t = tri(tuple(A), tuple(B), tuple(C), z=30.0)
+    t["nrm"][0] = [nvec] * 3
+    t["uv"][0] = [[0.30, 0.40]] * 3
+    lights = [((60.0, 40.0, -30.0), (9.0, 9.0, 9.0))]
+    eye = (0.0, 0.0, 1.0)
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_BUMP, tex=8, lights=lights, eye=eye))
+    assert rc == 0
+    x, y = 25, 9
+
+    def texel(u, v):                                   # TextureLoader::getTextureColor(vec2): clamp, truncate, black at the far edge
+        cu, cv = min(max(u, 0.0), 1.0), min(max(v, 0.0), 1.0)
+        cx, cy = int(cu * 8), int(cv * 8)
+        return np.zeros(3) if (cx >= 8 or cy >= 8) else tex[cy, cx].astype(float) / 255.0
+    n = nvec / np.linalg.norm(nvec)                    # the rasteriser hands the shader glm::normalize(interpolated normal)
+    s = np.sqrt(n[0] ** 2 + n[2] ** 2)
+    tv = np.array([n[0] * n[1] / s, s, n[2] * n[1] / s])
+    bv = np.cross(n, tv)
+    kh, kn = 0.2, 0.1
+    on = np.linalg.norm(texel(0.30, 0.40))
+    dU = kh * kn * (np.linalg.norm(texel((0.30 + 1) / 8, 0.40)) - on)
+    dV = kh * kn * (np.linalg.norm(texel(0.30, (0.40 + 1) / 8)) - on)
+    ln = np.array([-dU, -dV, 1.0])
+    nb = np.array([tv @ ln, bv @ ln, n @ ln])
+    nb = nb / np.linalg.norm(nb)
+    c = _blinn_phong64(np.array([x, y, 30.0], float), nb, texel(0.30, 0.40), eye, lights)
+    want = np.floor(np.clip(c, 0.0, 1.0) * 255.0)
+    got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
+    assert np.abs(got - want).max() <= 1.0 and got.max() > 3.0, (got, want, np.clip(c, 0, 1) * 255)
