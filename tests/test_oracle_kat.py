@@ -408,3 +408,42 @@ def test_bump_scalar_tail_known_value(orc):
     want = np.floor(np.clip(c, 0.0, 1.0) * 255.0)
     got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
     assert np.abs(got - want).max() <= 1.0 and got.max() > 3.0, (got, want, np.clip(c, 0, 1) * 255)
+
+
+def test_displacement_scalar_tail_known_value(orc):
+    """calcDisplacementMapping (src/Shader.cpp:447-475): the same perturbed normal as the bump shader AND the position moved along the
+    ORIGINAL normal by kn * |texel| before the Blinn-Phong sum"""
+    A, B, C = np.array([8.0, 8.0]), np.array([8.0, 28.5]), np.array([28.5, 8.0])
+    rng = np.random.default_rng(12)
+    tex = rng.integers(40, 216, (8, 8, 3)).astype(np.uint8)
+    orc.texture_set(9, tex)
+    nvec = np.array([-0.4, 0.2, -0.7])
+    t = tri(tuple(A), tuple(B), tuple(C), z=30.0)
+    t["nrm"][0] = [nvec] * 3
+    t["uv"][0] = [[0.55, 0.20]] * 3
+    lights = [((50.0, 35.0, -20.0), (7.0, 8.0, 9.0)), ((10.0, 2.0, 60.0), (2.0, 2.0, 2.0))]
+    eye = (0.0, 0.0, 1.0)
+    rc, pl, _ = orc.draw(frame(t, shader=abi.SHADER_DISPLACEMENT, tex=9, lights=lights, eye=eye))
+    assert rc == 0
+    x, y = 25, 9
+
+    def texel(u, v):
+        cu, cv = min(max(u, 0.0), 1.0), min(max(v, 0.0), 1.0)
+        cx, cy = int(cu * 8), int(cv * 8)
+        return np.zeros(3) if (cx >= 8 or cy >= 8) else tex[cy, cx].astype(float) / 255.0
+    n = nvec / np.linalg.norm(nvec)
+    s = np.sqrt(n[0] ** 2 + n[2] ** 2)
+    tv = np.array([n[0] * n[1] / s, s, n[2] * n[1] / s])
+    bv = np.cross(n, tv)
+    kh, kn = 0.2, 0.1
+    on = np.linalg.norm(texel(0.55, 0.20))
+    dU = kh * kn * (np.linalg.norm(texel((0.55 + 1) / 8, 0.20)) - on)
+    dV = kh * kn * (np.linalg.norm(texel(0.55, (0.20 + 1) / 8)) - on)
+    ln = np.array([-dU, -dV, 1.0])
+    nd = np.array([tv @ ln, bv @ ln, n @ ln])
+    nd = nd / np.linalg.norm(nd)
+    P = np.array([x, y, 30.0], float) + kn * n * on
+    c = _blinn_phong64(P, nd, texel(0.55, 0.20), eye, lights)
+    want = np.floor(np.clip(c, 0.0, 1.0) * 255.0)
+    got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
+    assert np.abs(got - want).max() <= 1.0 and got.max() > 3.0, (got, want, np.clip(c, 0, 1) * 255)
