@@ -447,3 +447,34 @@ def test_displacement_scalar_tail_known_value(orc):
     want = np.floor(np.clip(c, 0.0, 1.0) * 255.0)
     got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
     assert np.abs(got - want).max() <= 1.0 and got.max() > 3.0, (got, want, np.clip(c, 0, 1) * 255)
+
+
+def test_texture_two_lights_known_value_v_class(orc):
+    """an 8-wide-column pixel of the TEXTURE shader under two coloured lights: BlinnPhong<__m256> (include/shader/Shader.hpp:104-229) in
+    closed form — attenuation 1 / |dxy| (2-D), normalised light and half vectors, x^150, kd = the texel picked by round-half-even of
+    the clamped u * w (include/loader/TextureLoader.hpp:26-74) — summed, clamped, times 255, NOT truncated"""
+    A, B, C = np.array([8.0, 8.0]), np.array([8.0, 28.5]), np.array([28.5, 8.0])
+    rng = np.random.default_rng(13)
+    tex = rng.integers(30, 226, (8, 8, 3)).astype(np.uint8)
+    orc.texture_set(10, tex)
+    nrm = np.array([[0.1, -0.2, -1.0], [0.3, 0.1, -0.9], [-0.2, 0.2, -0.95]])
+    uv = np.array([[0.10, 0.20], [0.30, 0.85], [0.90, 0.35]])
+    t = tri(tuple(A), tuple(B), tuple(C), z=(20.0, 35.0, 50.0))
+    t["nrm"][0], t["uv"][0] = nrm, uv
+    lights = [((45.0, 20.0, -15.0), (5.0, 7.0, 9.0)), ((3.0, 40.0, -40.0), (4.0, 3.0, 2.0))]
+    eye = (0.0, 0.0, 1.0)
+    rc, pl, st = orc.draw(frame(t, shader=abi.SHADER_TEXTURE, tex=10, lights=lights, eye=eye))
+    assert rc == 0 and st["n_culled"] == 0
+    for (x, y) in ((12, 9), (15, 14), (20, 10)):
+        al, be, ga = _bary(np.array([float(x), float(y)]), A, B, C)
+        assert min(al, be, ga) > 0
+        z = al * 20.0 + be * 35.0 + ga * 50.0
+        n = al * nrm[0] + be * nrm[1] + ga * nrm[2]
+        u, v = al * uv[0] + be * uv[1] + ga * uv[2]
+        col, row = int(np.rint(min(max(u * 8, 0.0), 7.0))), int(np.rint(min(max(v * 8, 0.0), 7.0)))
+        kd = tex[row, col].astype(float) / 255.0
+        c = _blinn_phong64(np.array([x, y, z], float), n, kd, eye, lights)
+        want = np.clip(c, 0.0, 1.0) * 255.0
+        got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
+        assert np.abs(got - want).max() < 0.02, (x, y, got, want)
+        assert got.max() > 1.0
