@@ -478,3 +478,56 @@ def test_texture_two_lights_known_value_v_class(orc):
         got = np.array([pl[1][y, x], pl[2][y, x], pl[3][y, x]])
         assert np.abs(got - want).max() < 0.02, (x, y, got, want)
         assert got.max() > 1.0
+
+
+def test_vertex_stage_of_a_whole_mesh_against_glm_formulas_in_binary64(orc):
+    """Scene::loadTriangleStream (src/Scene.cpp:903-964) for the spot mesh, rotated, scaled and translated: the matrices of SURVEY.md
+    Appendix B (glm::translate / rotate / scale, lookAtLH, perspectiveLH_NO with the raw 45 as radians, the NDC matrix with its x
+    stretch) written out in numpy binary64, positions divided by w, depth remapped to [near, far], normals through the
+    inverse-transpose of the model matrix with w = 1 and divided by w"""
+    import scenes
+    verts, faces = scenes.mesh(scenes.SPOT_OBJ)
+    W, H, deg, tr, sc = 1920, 1080, 37.0, (-0.25, 0.05, 0.02), 0.3
+    eye, center, up = np.array(scenes.EYE, float), np.zeros(3), np.array([0.0, 1.0, 0.0])
+    got = scenes.mesh_stream(scenes.SPOT_OBJ, W, H, deg, tr, sc)
+
+    def translate(t):
+        m = np.eye(4)
+        m[:3, 3] = t
+        return m
+
+    def rotate(a, axis):                                  # glm::rotate: Rodrigues
+        n = np.asarray(axis, float) / np.linalg.norm(axis)
+        c, s = np.cos(a), np.sin(a)
+        K = np.array([[0, -n[2], n[1]], [n[2], 0, -n[0]], [-n[1], n[0], 0]])
+        m = np.eye(4)
+        m[:3, :3] = c * np.eye(3) + s * K + (1 - c) * np.outer(n, n)
+        return m
+    M = translate(tr) @ rotate(np.radians(deg), (0, 1, 0)) @ np.diag([sc, sc, sc, 1.0])
+    f = (center - eye) / np.linalg.norm(center - eye)
+    s_ = np.cross(up, f)
+    s_ /= np.linalg.norm(s_)
+    u_ = np.cross(f, s_)
+    V = np.eye(4)
+    V[0, :3], V[1, :3], V[2, :3] = s_, u_, f
+    V[:3, 3] = [-s_ @ eye, -u_ @ eye, -f @ eye]
+    n_, f_, aspect = 0.1, 100.0, W / H
+    tg = np.tan(45.0 / 2.0)                               # the degrees fed as radians (src/Scene.cpp:293)
+    P = np.zeros((4, 4))
+    P[0, 0], P[1, 1], P[2, 2], P[2, 3], P[3, 2] = 1 / (aspect * tg), 1 / tg, (f_ + n_) / (f_ - n_), -2 * f_ * n_ / (f_ - n_), 1.0
+    N = np.eye(4)
+    N[0, 0], N[1, 1], N[0, 3], N[1, 3] = W / 2 * aspect, H / 2, W / 2, H / 2
+    full = N @ P @ V @ M
+    NM = np.linalg.inv(M).T
+    p = np.c_[verts[:, :3].astype(float), np.ones(len(verts))] @ full.T
+    p = p[:, :3] / p[:, 3:4]
+    p[:, 2] = p[:, 2] * ((f_ - n_) / 2) + (f_ + n_) / 2
+    nn = np.c_[verts[:, 3:6].astype(float), np.ones(len(verts))] @ NM.T
+    nn = nn[:, :3] / nn[:, 3:4]
+    want_pos, want_nrm = p[faces], nn[faces]
+    assert got["pos"].shape == want_pos.shape == (len(faces), 3, 3)
+    assert np.abs(got["pos"][:, :, :2] - want_pos[:, :, :2]).max() < 2e-2      # pixels (binary32 chain against binary64)
+    assert np.abs(got["pos"][:, :, 2] - want_pos[:, :, 2]).max() < 2e-3        # depth in [0.1, 100]
+    assert np.abs(got["nrm"] - want_nrm).max() < 1e-4 * np.abs(want_nrm).max()
+    assert np.array_equal(got["uv"], verts[:, 6:8][faces])
+    assert want_pos[:, :, 0].min() > 0 and want_pos[:, :, 0].max() < W and want_pos[:, :, 1].min() > 0 and want_pos[:, :, 1].max() < H   # on screen
