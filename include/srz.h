@@ -321,6 +321,13 @@ int srz_verify_fastdiv(srz_ctx *ctx, uint64_t *out3);
  * out4 = { operands, results that differ although the flag was clear (must be 0), flagged operands with a normal result >= 2^-120
  * (ambiguous roundings), flagged operands with a smaller result } — the tiles of flagged pixels are shaded by the generic build. */
 int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4);
+/* Same for the attenuation distance of the scalar Blinn-Phong, sqrt(dx^2 + dy^2) evaluated in binary64 and rounded once
+ * (src/Shader.cpp:516-523 of the reference): the FAST builds take two binary64 Heron steps from the binary32 root instead of the
+ * binary64 square root, with a flag when the result lies within 8 binary64 ulps of a binary32 rounding boundary.  4.3e9 pseudo-random
+ * pairs (random / close exponents / few significant bits / scaled Pythagorean pairs whose root IS a rounding boundary):
+ * out5 = { pairs, results that differ although the flag was clear (must be 0), flagged random pairs, flagged Pythagorean pairs,
+ * flagged few-significant-bit pairs }. */
+int srz_verify_fastlen(srz_ctx *ctx, uint64_t *out5);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
 

@@ -533,6 +533,9 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     if (size_only) continue; // (the creation-time pass ends with the binning)
     if (detailed) HIP_TRY(ctx, hipEventRecord(ep.t1, s));
     unsigned ev = 0;
+    // SRZ_CLEAR_AT=1 (diagnostic, A/B): the clear starts beside k_shade instead of beside k_raster
+    static const bool clear_late = getenv("SRZ_CLEAR_AT") && atoi(getenv("SRZ_CLEAR_AT")) == 1;
+    if (side && clear_late) launch_raster(v, n, stats, s);
     if (side) {
       ev = ctx->ev_next++ % srz_ctx::EV_RING;
       HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[ev], s));
@@ -544,7 +547,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       if (int rc = copy_demand(side_s)) return rc;
       HIP_TRY(ctx, hipEventRecord(ctx->ev_join[ev], side_s));
     }
-    launch_raster(v, n, stats, s);
+    if (!(side && clear_late)) launch_raster(v, n, stats, s);
     if (turns) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_raster[ctx->raster_next++ % srz_ctx::EV_RING], s));
       ctx->raster_last_stream = s, ctx->raster_valid = true;
@@ -1275,6 +1278,18 @@ int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4) {
   HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 4; ++i) out4[i] = h[i];
+  return SRZ_OK;
+}
+
+int srz_verify_fastlen(srz_ctx *ctx, uint64_t *out5) {
+  if (!ctx || !out5) return SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 5 * sizeof(unsigned long long), ctx->stream));
+  launch_verify_fastlen(ctx->d_stats, ctx->stream);
+  unsigned long long h[5];
+  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 5; ++i) out5[i] = h[i];
   return SRZ_OK;
 }
 

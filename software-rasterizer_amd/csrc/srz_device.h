@@ -183,6 +183,7 @@ void launch_deinterleave(const void *gathered, void *full, uint32_t world, uint3
 void launch_verify_fastmath(unsigned long long *d_out4, hipStream_t s);
 void launch_verify_fastdiv(unsigned long long *d_out3, hipStream_t s);
 void launch_verify_fastpow(unsigned long long *d_out3, float p, hipStream_t s);
+void launch_verify_fastlen(unsigned long long *d_out4, hipStream_t s);
 void launch_tex_convert(const uint8_t *d_bgr, int w, int h, int row_stride, uint32_t *d_bgrx, hipStream_t s);
 
 } // namespace srz

@@ -126,6 +126,31 @@ __device__ __forceinline__ float len2d_f64(float a, float b) {
   const double dx = (double)a, dy = (double)b;
   return (float)__builtin_sqrt(dx * dx + dy * dy);
 }
+// The same value without the compiler's binary64 square root (v_rsq_f64 + three refinements + range scaling: ~22 binary64-rate
+// instructions per light in every S pixel): two Heron steps in binary64 from the binary32 root,
+//   s   = RN64(a^2 + b^2) exactly as the reference has it (both squares are exact in binary64: one fma);
+//   r   = the binary32 square root of RN32(s) (sqrt_core: |r - sqrt(s)| < 2^-23.4 r), h = v_rsq_f32 / 2 (|2 h r - 1| < 2^-21.5);
+//   R1  = r + (s - r^2) h    : r^2 is exact (48 bits); |R1 - sqrt(s)| < (2^-21.5 * 2^-23.4 + 2^-47.8 + 2^-52) R1 < 2^-44.7 R1
+//   R2  = R1 + (s - R1^2) h  : the residual is one fma (a single rounding of the exact s - R1^2); h's error now contributes 2^-66,
+//         the dropped second-order term 2^-90: R2 = sqrt(s) up to ITS OWN rounding, i.e. RN64(sqrt(s)) or a neighbour of it.
+// RN32(R2) is therefore the reference's RN32(RN64(sqrt(s))) unless a binary32 rounding boundary (the 29 dropped bits =
+// 0x10000000) lies within an ulp of R2: `amb` is set within 8 ulps — 3e-8 of the operands — and k_shade hands that tile to the
+// generic build like any operand outside FastMath's range.  `sbits` returns the bits of RN32(s) for the range tracking: inside
+// [2^-100, 2^101) everything above is normal.  Checked on the device against len2d_f64 (k_verify_fastlen, tests/test_gpu_fastmath.py).
+__device__ __forceinline__ float len2d_fast(float a, float b, bool &amb, uint32_t &sbits) {
+  const double dx = (double)a, dy = (double)b;
+  const double s = __builtin_fma(dx, dx, dy * dy);
+  const float sf = (float)s;
+  sbits = f2u_(sf);
+  const float rs = __builtin_amdgcn_rsqf(sf), r0 = sf * rs, h = 0.5f * rs;
+  const float r = __builtin_fmaf(__builtin_fmaf(-r0, r0, sf), h, r0);
+  const double R = (double)r, H = (double)h;
+  const double R1 = __builtin_fma(__builtin_fma(-R, R, s), H, R);
+  const double R2 = __builtin_fma(__builtin_fma(-R1, R1, s), H, R1);
+  const uint32_t lo = (uint32_t)__builtin_bit_cast(uint64_t, R2) & 0x1fffffffu;
+  amb |= (lo - 0x0ffffff8u) <= 16u; // within 8 binary64 ulps of the binary32 midpoint pattern
+  return (float)R2;
+}
 struct BranchMath {
   __device__ __forceinline__ float rcp(float x) { return rcp_rn(x); }
   __device__ __forceinline__ float sqrt(float x) { return sqrt_rn(x); }
@@ -170,7 +195,13 @@ struct FastMath {
     track(f2u_(d));
     return rcp_core(sqrt_core(d));
   }
-  __device__ __forceinline__ float len2d(float a, float b) { return len2d_f64(a, b); }
+  // (the scalar path's attenuation distance: two binary64 Heron steps from the binary32 root; an ambiguous rounding → `bad`)
+  __device__ __forceinline__ float len2d(float a, float b) {
+    uint32_t sb;
+    const float d = len2d_fast(a, b, bad, sb);
+    track(sb);
+    return d;
+  }
 };
 // ApproxMath — the TOLERANCE mode (SRZ_OPT_APPROX_SHADE, opt-in; never the default): the arithmetic CLASS of the reference's own
 // x86 path, which shades with approximate instructions — _mm256_rcp_ps (include/shader/Shader.hpp:131, src/Tools.cpp:19,
@@ -2712,6 +2743,53 @@ void launch_verify_fastdiv(unsigned long long *d_out, hipStream_t s) {
   hipLaunchKernelGGL(k_verify_fastdiv, dim3(8192), dim3(256), 0, s, d_out, 2048u);
 }
 
+// Check of len2d_fast (two binary64 Heron steps from the binary32 root) against len2d_f64 (the compiler's correctly rounded binary64
+// square root) on pseudo-random pairs: out[0] = pairs, out[1] = results that differ although the flag was clear (must be 0),
+// out[2] = flagged pairs among the random ones (must stay rare), out[3] = among the Pythagorean ones, out[4] = among the
+// few-significant-bit ones (exact roots and exact ties are common there).  A quarter of
+// the pairs each: random mantissas with independent exponents 2^-30 .. 2^40; the same with exponents at most two apart (both
+// squares matter); few significant bits (exact and near-exact roots); scaled Pythagorean pairs (m^2 - n^2, 2 m n) whose root
+// m^2 + n^2 is an odd number of up to 25 bits — exactly ON a binary32 rounding boundary when it exceeds 2^24 (those must be flagged
+// or equal: the reference's tie goes to even).
+__global__ void k_verify_fastlen(unsigned long long *out, uint32_t per_thread) {
+  unsigned long long bad = 0, flagged = 0, flagged_p = 0, flagged_f = 0, n = 0;
+  uint64_t st = mix64(0x5eedull + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x);
+  for (uint32_t i = 0; i < per_thread; ++i) {
+    st = mix64(st);
+    uint32_t ua = (uint32_t)st, ub = (uint32_t)(st >> 32);
+    const uint32_t mode = i & 3u;
+    float a, b;
+    if (mode == 3u) {
+      const uint32_t m = 2u + (ua >> 8) % 4094u;           // 2 .. 4095
+      uint32_t k = 1u + (ub >> 8) % (m - 1u);              // 1 .. m - 1
+      if (((m ^ k) & 1u) == 0u) k = k > 1u ? k - 1u : 2u;  // opposite parity (m = 2: k = 1)
+      if (k >= m) k = m - 1u;
+      const int e = (int)(ua & 31u) - 16;
+      a = __builtin_ldexpf((float)(m * m - k * k), e), b = __builtin_ldexpf((float)(2u * m * k), e); // (both exact)
+      if (ub & 1u) a = -a;
+    } else {
+      const uint32_t ea = 97u + ((ua >> 23) & 0xffu) % 71u;
+      uint32_t eb = 97u + ((ub >> 23) & 0xffu) % 71u;
+      if (mode == 1u) eb = ea + ((ub >> 23) & 3u) - 1u;
+      if (mode == 2u) ua &= ~0x3fffu << ((ub >> 28) & 7u), ub &= ~0xfffu << ((ua >> 28) & 7u);
+      a = u2f_((ua & 0x807fffffu) | (ea << 23)), b = u2f_((ub & 0x807fffffu) | (eb << 23));
+    }
+    bool amb = false;
+    uint32_t sb;
+    const float x = len2d_fast(a, b, amb, sb), y = len2d_f64(a, b);
+    ++n, bad += (!amb && f2u_(x) != f2u_(y)) ? 1 : 0;
+    if (amb) (mode == 3u ? flagged_p : mode == 2u ? flagged_f : flagged) += 1;
+  }
+  atomicAdd(&out[0], n);
+  if (bad) atomicAdd(&out[1], bad);
+  if (flagged) atomicAdd(&out[2], flagged);
+  if (flagged_p) atomicAdd(&out[3], flagged_p);
+  if (flagged_f) atomicAdd(&out[4], flagged_f);
+}
+void launch_verify_fastlen(unsigned long long *d_out4, hipStream_t s) {
+  hipLaunchKernelGGL(k_verify_fastlen, dim3(8192), dim3(256), 0, s, d_out4, 2048u);
+}
+
 // Exhaustive check of pow_fast against pow_cr: every binary32 x in [2^-40, 1] (+ the operands above 1 the clamped cosines can
 // reach by rounding) at exponent p.  out[0] = operands, out[1] = results that differ although pow_fast did NOT flag them (must
 // be 0), out[2] = flagged operands whose result is a normal binary32 >= 2^-120 (ambiguous roundings: must stay rare), out[3] =
@@ -2808,36 +2886,39 @@ void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t 
   static const uint32_t env_grid = getenv("SRZ_SHADE_GRID") ? (uint32_t)atoi(getenv("SRZ_SHADE_GRID")) : 0u;
   const uint32_t gcap = env_grid ? env_grid : (a.other_streams ? 2048u : 16384u);
   dim3 grid((std::min(max_tiles, gcap) + 7u) & ~7u); // (a multiple of 8: workgroup b serves list b % 8)
+  // SRZ_SHADE_LDS_PAD (diagnostic): bytes of unused dynamic LDS per workgroup — 1024 caps k_shade at five workgroups per CU, 6144 at
+  // four (26.3 KB static each, 160 KB per CU): how much room the other lane's k_raster waves find on a CU k_shade has filled
+  static const uint32_t pad = getenv("SRZ_SHADE_LDS_PAD") ? (uint32_t)atoi(getenv("SRZ_SHADE_LDS_PAD")) : 0u;
   if (stats) { // (counting runs shade every frame with the generic build: force_generic)
-    hipLaunchKernelGGL((k_shade<true, 0>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_shade<true, 0>), grid, dim3(256), pad, s, a);
     return;
   }
   // one FAST build per (light count, with / without BUMP or DISPLACEMENT batches) some frame of the set has:
   // fast_mask bit NL = plain, bit 8 + NL = with them
   if (approx) { // the tolerance mode's builds (classify_frames sets only the plain bits for the frames they shade)
-    if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false, true>), grid, dim3(256), 0, s, a);
-    if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false, true>), grid, dim3(256), 0, s, a);
-    if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false, true>), grid, dim3(256), 0, s, a);
-    if (fast_mask & 16u) hipLaunchKernelGGL((k_shade<false, 4, false, true>), grid, dim3(256), 0, s, a);
+    if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false, true>), grid, dim3(256), pad, s, a);
+    if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false, true>), grid, dim3(256), pad, s, a);
+    if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false, true>), grid, dim3(256), pad, s, a);
+    if (fast_mask & 16u) hipLaunchKernelGGL((k_shade<false, 4, false, true>), grid, dim3(256), pad, s, a);
     fast_mask = 0;
   }
-  if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 16u) hipLaunchKernelGGL((k_shade<false, 4, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x200u) hipLaunchKernelGGL((k_shade<false, 1, true>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x400u) hipLaunchKernelGGL((k_shade<false, 2, true>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x800u) hipLaunchKernelGGL((k_shade<false, 3, true>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x1000u) hipLaunchKernelGGL((k_shade<false, 4, true>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 2u) hipLaunchKernelGGL((k_shade<false, 1, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 4u) hipLaunchKernelGGL((k_shade<false, 2, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 8u) hipLaunchKernelGGL((k_shade<false, 3, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 16u) hipLaunchKernelGGL((k_shade<false, 4, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x200u) hipLaunchKernelGGL((k_shade<false, 1, true>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x400u) hipLaunchKernelGGL((k_shade<false, 2, true>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x800u) hipLaunchKernelGGL((k_shade<false, 3, true>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x1000u) hipLaunchKernelGGL((k_shade<false, 4, true>), grid, dim3(256), pad, s, a);
   // ... and per light count with a non-integer exponent: bit 16 + NL
-  if (fast_mask & 0x20000u) hipLaunchKernelGGL((k_shade<false, -1, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x40000u) hipLaunchKernelGGL((k_shade<false, -2, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x80000u) hipLaunchKernelGGL((k_shade<false, -3, false>), grid, dim3(256), 0, s, a);
-  if (fast_mask & 0x100000u) hipLaunchKernelGGL((k_shade<false, -4, false>), grid, dim3(256), 0, s, a);
+  if (fast_mask & 0x20000u) hipLaunchKernelGGL((k_shade<false, -1, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x40000u) hipLaunchKernelGGL((k_shade<false, -2, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x80000u) hipLaunchKernelGGL((k_shade<false, -3, false>), grid, dim3(256), pad, s, a);
+  if (fast_mask & 0x100000u) hipLaunchKernelGGL((k_shade<false, -4, false>), grid, dim3(256), pad, s, a);
   // the generic build also serves the tiles the FAST builds hand back: when no frame is generic that is normally
   // nothing, and a small grid does
   dim3 ggrid(any_generic ? grid.x : (grid.x < 128u ? grid.x : 128u));
-  hipLaunchKernelGGL((k_shade<false, 0>), ggrid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_shade<false, 0>), ggrid, dim3(256), pad, s, a);
 }
 
 bool raster_four_waves(const RenderArgs &a) { return a.n_frames * a.n_local_bands * a.tiles_x <= 4096u; }

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_set_option", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_verify_fastpow", "srz_draw_batch",
+           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_verify_fastpow", "srz_verify_fastlen", "srz_draw_batch",
            "srz_comm_unique_id", "srz_comm_create", "srz_comm_destroy", "srz_frameset_exchange_bytes", "srz_frameset_allgather",
            "srz_frameset_deinterleave", "srz_frameset_allgather_inplace", "srz_frameset_gathered_row_offset",
            "srz_frameset_read_gathered_frame"]
@@ -77,6 +77,7 @@ def lib():
         L.srz_verify_fastmath.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_verify_fastdiv.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_verify_fastpow.argtypes = [vp, C.c_float, C.POINTER(C.c_uint64)]
+        L.srz_verify_fastlen.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_comm_unique_id.argtypes = [vp]
         L.srz_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.srz_comm_destroy.argtypes = [vp, vp]
@@ -302,6 +303,11 @@ class Context:
     def verify_fastpow(self, p):
         out = (C.c_uint64 * 4)()
         self._check(lib().srz_verify_fastpow(self.h, float(p), out))
+        return [int(x) for x in out]
+
+    def verify_fastlen(self):
+        out = (C.c_uint64 * 5)()
+        self._check(lib().srz_verify_fastlen(self.h, out))
         return [int(x) for x in out]
 
     def debug_counters(self):

@@ -34,9 +34,12 @@ def test_default_line_is_short_last_and_carries_every_config():
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.2 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert 0.1 < roof["frac_unprimed"] < 1.0
+    # the fraction against BOTH peaks: 8.0 TB/s spec and the 6.29 TB/s measured copy
+    assert roof["peak_measured"] == 6290.0 and abs(roof["frac_measured"] - roof["achieved"] / 6290.0) < 1e-3 and roof["frac"] < roof["frac_measured"] < 1.3
     assert (roof["traffic"] is None) == bool(roof.get("traffic_stale"))          # fresh counters, or flagged — never silently old ones
     for k in ("c3", "c4", "c5"):                                                  # flat scalars: what the driver's parser keeps
         assert 0.05 < roof["frac_" + k] < 1.0 and roof["fps_" + k] > 0
+        assert abs(roof["frac_measured_" + k] - roof["frac_" + k] * 8000.0 / 6290.0) < 2e-3
     pc = roof["per_config"]
     for w in ("c3", "c4", "c5", "readme", "c2_p7.5", "c2:draw", "c2:approx", "c3:approx", "c4:approx", "c5:approx"):
         assert "error" not in pc[w], pc[w]

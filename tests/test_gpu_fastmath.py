@@ -40,3 +40,19 @@ def test_optimistic_pow_equals_the_correctly_rounded_one_wherever_it_does_not_fl
     # ambiguous roundings: within 32 + 4 p binary64 ulps of a binary32 rounding boundary = 2 (32 + 4 p) / 2^29 of the normal results
     # (the band of results 2^-151 .. 2^-120 is flagged wholesale and counted apart)
     assert flagged < 100 + n * 4 * (32 + 4 * p) / 2 ** 29, (p, flagged, flagged_small, n)
+
+
+def test_heron_distance_equals_the_binary64_square_root_wherever_it_does_not_flag():
+    """len2d_fast (the scalar Blinn-Phong's attenuation distance in the FAST k_shade builds: two binary64 Heron steps from the
+    binary32 root) against len2d_f64 (binary64 sqrt rounded once, src/Shader.cpp:516-523 of the reference) on 4.3e9 pseudo-random
+    pairs: bit-identical wherever the rounding-safety flag is clear; flagged pairs (their tile goes to the generic build) stay at
+    the 1e-7 level; Pythagorean pairs whose root is exactly a binary32 rounding boundary are flagged"""
+    import srz
+    ctx = srz.Context(0)
+    n, bad, flagged, flagged_pyth, flagged_fewbits = ctx.verify_fastlen()
+    ctx.close()
+    print("verify_fastlen", n, bad, flagged, flagged_pyth, flagged_fewbits)
+    assert n == 8192 * 256 * 2048
+    assert bad == 0, (bad, flagged, flagged_pyth, flagged_fewbits)
+    assert flagged < 1000 + n * 1e-6, (flagged, n)   # expected: 2 * 8 / 2^29 = 3e-8 of the random pairs (half of all pairs)
+    assert flagged_pyth > 1000, flagged_pyth       # roots m^2 + n^2 > 2^24 (odd) are ties: they must be noticed
