@@ -41,8 +41,10 @@ extern "C" {
  *   5  srz_set_option, srz_verify_fastpow; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
  *   6  SRZ_OPT_APPROX_SHADE (the tolerance mode of the shaders); srz_frameset_resolve8 / _deinterleave / the bgr8 exchange take any width;
  *      the tile-list pool is sized by srz_frameset_create / srz_sceneset_create, the first srz_frameset_render no longer blocks
+ *   7  srz_host_register / srz_host_unregister, SRZ_NO_Z_READBACK, srz_verify_fastlen; srz_draw_batch reads one piece of the batch
+ *      back while the next one renders
  */
-#define SRZ_ABI_VERSION 6
+#define SRZ_ABI_VERSION 7
 
 /* error codes */
 #define SRZ_OK 0
@@ -67,6 +69,9 @@ extern "C" {
 #define SRZ_EXACT_SPLIT 0u /* default: reproduce the reference's AVX-columns / scalar-tail split per (triangle,pixel) */
 #define SRZ_UNIFIED 1u     /* every pixel uses the 8-wide ("AVX") semantics; NOT reference-exact, for A/B only */
 #define SRZ_FUSED_CLEAR 2u /* treat z/colour as just cleared (clear(Color|Depth), src/Render.cpp:46-55): write-only framebuffer */
+#define SRZ_NO_Z_READBACK 8u /* srz_draw / srz_draw_scene / srz_draw_batch only: the depth plane is not copied back to the host (the caller
+                              * reads colour only: a quarter of the PCIe bytes less).  The caller's z buffer is then stale: use it
+                              * with SRZ_FUSED_CLEAR frames, i.e. where the next draw does not start from it */
 #define SRZ_ORDERED_RASTER 4u /* rasterise every tile with the reference's ordered triangle walk (src/Rasterizer.cpp:199-236)
                                * instead of the order-independent depth keys; same result bit for bit, slower; for A/B only */
 
@@ -201,7 +206,9 @@ int srz_draw(srz_ctx *ctx, int primitive, const srz_frame *frame, float *z, floa
 
 /* Batch form of srz_draw (host buffers): n frames of one size in one launch set.  planes[f] points to 4*W*H floats of
  * frame f laid out [z | c0 | c1 | c2], in/out like srz_draw's four pointers.  stats (optional) = sums over the batch.
- * One upload + one download over PCIe per call; for data that stays on the device use the frameset calls below. */
+ * The batch is rendered in pieces of ~128 MB of planes: piece k is read back on a second stream while piece k + 1 renders (and
+ * uploads its in/out planes); planes registered with srz_host_register move by DMA.  SRZ_NO_Z_READBACK (per frame) skips the depth
+ * plane's download.  For data that stays on the device use the frameset calls below. */
 int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_frames, float *const *planes,
                    srz_stats *stats);
 
@@ -310,6 +317,14 @@ int srz_kernel_time_samples(srz_ctx *ctx, float *out, int cap, int *n, double *s
  * render — every event is a barrier in the launch stream, ≈4 µs each, so throughput is measured with 1 and broken down with 2) */
 int srz_set_kernel_timing(srz_ctx *ctx, int enabled);
 int srz_sync(srz_ctx *ctx);
+/* Page-lock `bytes` of host memory at `ptr` / release it again (hipHostRegister / hipHostUnregister behind the C ABI, so that a
+ * binding needs no HIP header).  The host-buffer entry points — srz_draw, srz_draw_scene, srz_draw_batch — move planes that lie in a
+ * registered range by DMA at the link's rate instead of through the runtime's pageable staging copies (MI355X, 1024^2: see
+ * DESIGN.md §5 "PCIe-inclusive rate").  Register a buffer once after allocating it (the reference's m_zBuffer / m_channels live as
+ * long as the pipeline object), unregister it before freeing it.  What these calls replace on the reference's side: nothing — its
+ * framebuffer never leaves host memory (src/Render.cpp:46-64); this is the price of the seam at src/Rasterizer.cpp:183-240. */
+int srz_host_register(srz_ctx *ctx, void *ptr, size_t bytes);
+int srz_host_unregister(srz_ctx *ctx, void *ptr);
 /* self-check of the device arithmetic: compares the kernels' short exact reciprocal / square-root sequences with the
  * IEEE expansions on all 2^32 binary32 operands. out4 = {operands on the fast path, rcp, sqrt, 1/sqrt mismatches} */
 int srz_verify_fastmath(srz_ctx *ctx, uint64_t *out4);

@@ -63,6 +63,10 @@ struct srz_ctx {
   bool opt_approx_shade = false; // SRZ_OPT_APPROX_SHADE (srz_set_option): framesets created from now on shade in the tolerance mode
   bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
+  float *batch_out = nullptr;    // srz_draw_batch's device planes, kept between calls (grown on demand)
+  size_t batch_out_bytes = 0;
+  hipStream_t stream3 = nullptr; // srz_draw_batch: the read-back of one piece of the batch under the render of the next
+  hipEvent_t ev_piece[8] = {};   // (EV_RING of them: "piece k has been rendered")
   static constexpr int EV_RING = 8;  // fork/join events are used round-robin: a render never re-records an event that
   hipEvent_t ev_fork[EV_RING] = {}, ev_join[EV_RING] = {}; // a wait of the previous few renders may still refer to
   unsigned ev_next = 0;
@@ -368,8 +372,10 @@ int collect_events(srz_ctx *ctx) {
 // (one_frame_scratch: a counting run whose pixels nobody reads — every frame writes the SAME one-frame buffer)
 // (size_only: the creation-time pass of srz_frameset_create / srz_sceneset_create — setup + binning of every sub-batch and the sizing
 // of the tile-list pool by their demand, nothing rasterised, no texture needed yet)
+// (f_begin, f_count: only frames [f_begin, f_begin + f_count) of the set — srz_draw_batch renders a set in pieces so that the
+// read-back of one piece runs under the render of the next; d_out is the whole set's buffer either way)
 int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or, hipStream_t s, bool stats, bool one_frame_scratch = false,
-                bool size_only = false) {
+                bool size_only = false, int f_begin = 0, int f_count = -1) {
   if (fs->shard_rank != ctx->shard_rank || fs->shard_world != ctx->shard_world)
     return fail(ctx, SRZ_E_INVALID, "frameset was created under a different shard (call srz_set_shard before srz_frameset_create)");
   for (const BatchDesc &b : fs->h_batches) {
@@ -468,7 +474,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // A sub-batch is a view: every per-frame array from its first frame on; counters, record pool and work lists are shared
   // (k_setup resets them, and stream order keeps one sub-batch's kernels behind the previous one's).  Counting runs and the
   // per-kernel timing mode render in one piece.
-  const int n_all = fs->n_frames;
+  const int n_all = f_count < 0 ? fs->n_frames : f_count;
   int chunk = n_all;
   // The sub-batch size is 192 frames' worth of 1024^2 (≈ 197 k tiles: the measured sweet spot), in frames of THIS set — a
   // rank of an 8-GPU job holds an eighth of every frame and takes 1536 of them at a time; frames so large that fewer than 64
@@ -485,11 +491,12 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   for (int f0 = 0; f0 < n_all; f0 += chunk, ++part) {
     RenderArgs v = a;
     const int n = std::min(chunk, n_all - f0);
-    if (n != n_all) {
-      v.frames += f0, v.n_frames = (uint32_t)n;
-      v.vis += (size_t)f0 * tpf * ((size_t)TILE * TILE);
-      v.tile_info += (size_t)f0 * tpf;
-      v.out += (size_t)f0 * a.frame_stride;
+    if (n != fs->n_frames) {
+      const int fa = f_begin + f0; // (first frame of this piece in the set)
+      v.frames += fa, v.n_frames = (uint32_t)n;
+      v.vis += (size_t)fa * tpf * ((size_t)TILE * TILE);
+      v.tile_info += (size_t)fa * tpf;
+      v.out += (size_t)fa * a.frame_stride;
       v.work_cap = (uint32_t)((size_t)(n < 8 ? n : (n + 7) / 8) * tpf);
     }
     const uint32_t tiles = (uint32_t)((size_t)n * tpf);
@@ -647,6 +654,7 @@ void srz_destroy(srz_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->draw_fs) srz_frameset_destroy(ctx, ctx->draw_fs);
   (void)hipFree(ctx->draw_out);
+  (void)hipFree(ctx->batch_out);
   if (ctx->span_t0) (void)hipEventDestroy(ctx->span_t0);
   for (auto &ep : ctx->ev_used) ctx->ev_pool.push_back(ep);
   for (auto &ep : ctx->ev_pool) (void)hipEventDestroy(ep.t0), (void)hipEventDestroy(ep.t1), (void)hipEventDestroy(ep.t2), (void)hipEventDestroy(ep.t3);
@@ -658,6 +666,11 @@ void srz_destroy(srz_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream2);
     for (int i = 0; i < srz_ctx::EV_RING; ++i) (void)hipEventDestroy(ctx->ev_fork[i]), (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  if (ctx->stream3) {
+    (void)hipStreamSynchronize(ctx->stream3);
+    (void)hipStreamDestroy(ctx->stream3);
+    for (int i = 0; i < srz_ctx::EV_RING; ++i) (void)hipEventDestroy(ctx->ev_piece[i]);
   }
   if (ctx->ev_raster[0]) {
     for (int i = 0; i < srz_ctx::EV_RING; ++i) (void)hipEventDestroy(ctx->ev_raster[i]);
@@ -1490,6 +1503,22 @@ int srz_frameset_read_gathered_frame(srz_ctx *ctx, const srz_frameset *fs, const
   return SRZ_OK;
 }
 
+/* Page-locks `bytes` of the caller's memory at `ptr` (hipHostRegister): planes inside a registered range move between host and
+ * device by DMA at the link's rate in srz_draw / srz_draw_scene / srz_draw_batch instead of through the runtime's staging copies. */
+int srz_host_register(srz_ctx *ctx, void *ptr, size_t bytes) {
+  if (!ctx || !ptr || !bytes) return ctx ? fail(ctx, SRZ_E_INVALID, "srz_host_register: null argument") : SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return SRZ_OK;
+}
+int srz_host_unregister(srz_ctx *ctx, void *ptr) {
+  if (!ctx || !ptr) return ctx ? fail(ctx, SRZ_E_INVALID, "srz_host_unregister: null argument") : SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (nothing of ours may still be copying from / to the range)
+  HIP_TRY(ctx, hipHostUnregister(ptr));
+  return SRZ_OK;
+}
+
 int srz_sync(srz_ctx *ctx) {
   if (!ctx) return SRZ_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1573,7 +1602,9 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
     if (stats) rc = stats_pass(ctx, fs, fused ? nullptr : d_out, 0, s, stats);
     if (rc == SRZ_OK) rc = render_impl(ctx, fs, d_out, 0, s, false);
   }
-  for (int p = 0; p < 4 && e == hipSuccess && rc == SRZ_OK; ++p)
+  // (planes the caller page-locked with srz_host_register move by DMA straight from / to his memory; pageable ones through the
+  // runtime's staging buffers.  SRZ_NO_Z_READBACK: the depth plane stays on the device)
+  for (int p = (fflags & SRZ_NO_Z_READBACK) ? 1 : 0; p < 4 && e == hipSuccess && rc == SRZ_OK; ++p)
     e = hipMemcpyAsync(host[p], d_out + p * plane, pb, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return fail(ctx, SRZ_E_NODEVICE, std::string("srz_draw: ") + hipGetErrorString(e));
@@ -1604,26 +1635,65 @@ int srz_draw_batch(srz_ctx *ctx, int primitive, const srz_frame *frames, int n_f
   int rc = srz_frameset_create(ctx, frames, n_frames, &fs);
   if (rc) return rc;
   const size_t fb = 4ull * (size_t)fs->width * (size_t)fs->height * sizeof(float); // one frame: z,c0,c1,c2 planes
-  float *d_out = nullptr;
-  hipError_t e = hipMalloc(&d_out, fb * (size_t)n_frames);
-  if (e != hipSuccess) {
-    srz_frameset_destroy(ctx, fs);
-    return fail(ctx, SRZ_E_NOMEM, "srz_draw_batch: hipMalloc failed");
-  }
-  hipStream_t s = ctx->stream;
-  for (int f = 0; f < n_frames && e == hipSuccess; ++f) // accumulate-mode frames start from the caller's planes
-    if (!(frames[f].flags & SRZ_FUSED_CLEAR))
-      e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_out) + fb * f, planes[f], fb, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) {
-    if (stats) { // (frames with SRZ_FUSED_CLEAR ignore what the scratch copy holds)
-      rc = stats_pass(ctx, fs, d_out, 0, s, stats);
+  // (the device planes are kept between calls: allocating and freeing half a gigabyte costs as much as moving it)
+  hipError_t e = hipSuccess;
+  if (ctx->batch_out_bytes < fb * (size_t)n_frames) {
+    (void)hipFree(ctx->batch_out);
+    ctx->batch_out = nullptr, ctx->batch_out_bytes = 0;
+    e = hipMalloc(&ctx->batch_out, fb * (size_t)n_frames);
+    if (e != hipSuccess) {
+      srz_frameset_destroy(ctx, fs);
+      return fail(ctx, SRZ_E_NOMEM, "srz_draw_batch: hipMalloc failed");
     }
-    if (rc == SRZ_OK) rc = render_impl(ctx, fs, d_out, 0, s, false);
+    ctx->batch_out_bytes = fb * (size_t)n_frames;
   }
-  for (int f = 0; f < n_frames && e == hipSuccess && rc == SRZ_OK; ++f)
-    e = hipMemcpyAsync(planes[f], reinterpret_cast<uint8_t *>(d_out) + fb * f, fb, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(d_out);
+  float *d_out = ctx->batch_out;
+  hipStream_t s = ctx->stream;
+  // The set is rendered in pieces of whole frames (~128 MB of planes each), all enqueued at once; a second stream brings piece k
+  // back to the caller's planes while piece k + 1 renders (and, for accumulate-mode frames, while its planes go up) — with planes
+  // the caller page-locked (srz_host_register) both directions are DMA at the link's rate, pageable ones go through the runtime's
+  // staging copies.  A counting run (stats) renders in one piece first.
+  if (!ctx->stream3) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    for (int i = 0; i < srz_ctx::EV_RING; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_piece[i], hipEventDisableTiming));
+  }
+  const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)128 << 20) / fb));
+  const int n_pieces = (n_frames + per - 1) / per;
+  const size_t plane_b = fb / 4;
+  if (stats) { // (frames with SRZ_FUSED_CLEAR ignore what the scratch copy holds)
+    for (int f = 0; f < n_frames && e == hipSuccess; ++f)
+      if (!(frames[f].flags & SRZ_FUSED_CLEAR))
+        e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_out) + fb * f, planes[f], fb, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = stats_pass(ctx, fs, d_out, 0, s, stats);
+  }
+  // (piece k's read-back is issued AFTER piece k + 1's render has been enqueued: a copy to pageable memory holds the calling thread
+  // until it is done, and the device must have its next piece by then)
+  auto read_back = [&](int k) {
+    const int f0 = k * per, n = std::min(per, n_frames - f0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream3, ctx->ev_piece[k % srz_ctx::EV_RING], 0); // "piece k has been rendered"
+    for (int f = f0; f < f0 + n && e == hipSuccess; ++f) {
+      const size_t skip = (frames[f].flags & SRZ_NO_Z_READBACK) ? plane_b : 0; // (the depth plane is the first of a frame's four)
+      e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(planes[f]) + skip, reinterpret_cast<uint8_t *>(d_out) + fb * f + skip, fb - skip,
+                         hipMemcpyDeviceToHost, ctx->stream3);
+    }
+  };
+  for (int k = 0; k < n_pieces && e == hipSuccess && rc == SRZ_OK; ++k) {
+    const int f0 = k * per, n = std::min(per, n_frames - f0);
+    if (!stats) // accumulate-mode frames start from the caller's planes (a counting run has uploaded them already)
+      for (int f = f0; f < f0 + n && e == hipSuccess; ++f)
+        if (!(frames[f].flags & SRZ_FUSED_CLEAR))
+          e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_out) + fb * f, planes[f], fb, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) break;
+    rc = render_impl(ctx, fs, d_out, 0, s, false, false, false, f0, n);
+    if (rc != SRZ_OK) break;
+    e = hipEventRecord(ctx->ev_piece[k % srz_ctx::EV_RING], s); // (slot k % 8 was last waited for by piece k - 8's read-back, issued long ago)
+    if (k > 0) read_back(k - 1);
+  }
+  if (e == hipSuccess && rc == SRZ_OK) read_back(n_pieces - 1);
+  { // both streams drain before the buffers go, whatever happened above
+    const hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(ctx->stream3);
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+  }
   srz_frameset_destroy(ctx, fs);
   if (e != hipSuccess) return fail(ctx, SRZ_E_NODEVICE, std::string("srz_draw_batch: ") + hipGetErrorString(e));
   return rc;

@@ -107,6 +107,7 @@ struct Decoder {
   const std::string &path;
   int W = 0, H = 0, ncomp = 0, hmax = 1, vmax = 1;
   bool progressive = false, adobe = false;
+  int n_scans = 0;
   int adobe_transform = -1, restart_interval = 0;
   uint16_t qt[4][64];
   bool qt_ok[4] = {false, false, false, false};
@@ -184,7 +185,9 @@ struct Decoder {
         if (have_sof) fail("two frame headers");
         if (n < 6 || s[0] != 8) fail("only 8-bit samples");
         H = s[1] << 8 | s[2], W = s[3] << 8 | s[4], ncomp = s[5];
-        if (W <= 0 || H <= 0 || W > 32768 || H > 32768 || (size_t)W * (size_t)H > ((size_t)1 << 28)) fail("bad size"); // (bounds the allocations below)
+        // (bounds the allocations below — coefficients, planes and the image together take ~15 bytes per pixel: at most 1 GB — and,
+        // with the scan limit, the time a crafted progressive file can cost)
+        if (W <= 0 || H <= 0 || W > 32768 || H > 32768 || (size_t)W * (size_t)H > ((size_t)1 << 26)) fail("bad size");
         if ((ncomp != 1 && ncomp != 3) || n < 6 + 3 * (size_t)ncomp) fail("only 1 or 3 components");
         for (int c = 0; c < ncomp; ++c) {
           comp[c].id = s[6 + 3 * c], comp[c].h = s[7 + 3 * c] >> 4, comp[c].v = s[7 + 3 * c] & 15, comp[c].tq = s[8 + 3 * c] & 3;
@@ -218,6 +221,7 @@ struct Decoder {
 
   // one scan: header at s, entropy-coded data from `at` → the offset behind it
   size_t scan(size_t at, const uint8_t *s, size_t n) {
+    if (++n_scans > 1024) fail("too many scans"); // (libjpeg-turbo's own guard against progressive files made of empty scans)
     if (n < 1) fail("bad SOS");
     const int ns = s[0];
     if (ns < 1 || ns > ncomp || n < 1 + 2 * (size_t)ns + 3) fail("bad SOS");

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_set_option", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_verify_fastpow", "srz_verify_fastlen", "srz_draw_batch",
+           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_verify_fastpow", "srz_verify_fastlen", "srz_host_register", "srz_host_unregister", "srz_draw_batch",
            "srz_comm_unique_id", "srz_comm_create", "srz_comm_destroy", "srz_frameset_exchange_bytes", "srz_frameset_allgather",
            "srz_frameset_deinterleave", "srz_frameset_allgather_inplace", "srz_frameset_gathered_row_offset",
            "srz_frameset_read_gathered_frame"]
@@ -78,6 +78,8 @@ def lib():
         L.srz_verify_fastdiv.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_verify_fastpow.argtypes = [vp, C.c_float, C.POINTER(C.c_uint64)]
         L.srz_verify_fastlen.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.srz_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]
+        L.srz_host_unregister.argtypes = [vp, C.c_void_p]
         L.srz_comm_unique_id.argtypes = [vp]
         L.srz_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.srz_comm_destroy.argtypes = [vp, vp]
@@ -270,6 +272,13 @@ class Context:
         st = abi.SrzStats()
         self._check(lib().srz_draw_batch(self.h, primitive, abi.frames_array(frames), n, ptrs, C.byref(st) if want_stats else None))
         return planes, (st.as_dict() if want_stats else None)
+
+    def host_register(self, array):
+        """page-lock a numpy array's memory: srz_draw / srz_draw_batch then move planes inside it by DMA (srz_host_register)"""
+        self._check(lib().srz_host_register(self.h, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        self._check(lib().srz_host_unregister(self.h, array.ctypes.data))
 
     def frameset(self, frames):
         return FrameSet(self, frames)

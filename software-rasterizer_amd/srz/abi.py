@@ -7,12 +7,12 @@ import ctypes as C
 
 import numpy as np
 
-SRZ_ABI_VERSION = 6  # = include/srz.h; srz.lib() refuses a library that reports another one
+SRZ_ABI_VERSION = 7  # = include/srz.h; srz.lib() refuses a library that reports another one
 SRZ_OK = 0
 SRZ_E_INVALID, SRZ_E_NODEVICE, SRZ_E_NOMEM, SRZ_E_TEXTURE, SRZ_E_PRIMITIVE = -1, -2, -3, -4, -5
 SHADER_NORMAL, SHADER_TEXTURE, SHADER_PHONG, SHADER_DISPLACEMENT, SHADER_BUMP = 0, 1, 2, 3, 4
 PRIMITIVE_LINES, PRIMITIVE_TRIANGLES = 0, 1
-EXACT_SPLIT, UNIFIED, FUSED_CLEAR, ORDERED_RASTER = 0, 1, 2, 4
+EXACT_SPLIT, UNIFIED, FUSED_CLEAR, ORDERED_RASTER, NO_Z_READBACK = 0, 1, 2, 4, 8
 EXCHANGE_PLANES, EXCHANGE_BGR8 = 0, 1
 OPT_POOL_LAZY, OPT_APPROX_SHADE = 1, 2  # srz_set_option
 

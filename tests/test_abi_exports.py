@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert name in declared_functions()
     from srz import abi
     header = int(re.search(r"#define SRZ_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "srz.h")).read()).group(1))
-    assert lib.srz_abi_version() == header == abi.SRZ_ABI_VERSION == 6
+    assert lib.srz_abi_version() == header == abi.SRZ_ABI_VERSION == 7
 
 
 def test_binding_refuses_a_library_of_another_abi_version(tmp_path):

@@ -247,6 +247,48 @@ def test_draw_batch_host_buffers_equal_per_frame_draw(orc):
     ctx.close()
 
 
+def test_draw_batch_in_pieces_with_registered_planes_and_without_the_depth_readback(orc):
+    """srz_draw_batch renders a batch in pieces of ~128 MB of planes and reads piece k back while piece k + 1 renders: 40 frames of
+    1024 x 512 (8 MB each: three pieces of 16 / 16 / 8) in page-locked planes (srz_host_register) — every frame equals the oracle bit
+    for bit, accumulate-mode frames in the middle of a piece included; frames flagged SRZ_NO_Z_READBACK leave the caller's depth
+    plane untouched; srz_draw with registered planes and the flag likewise"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(0, scenes.spot_texture())
+    uniq = [scenes.config2(i, size=512).tris[0] for i in range(6)]
+    W, H = 1024, 512
+
+    def wide(i, flags):  # config 2's 512 x 512 triangles on a 1024 x 512 frame (a frame object of its own: with_flags() mutates)
+        return abi.Frame(W, H, scenes.EYE, scenes.LIGHTS, [(abi.SHADER_TEXTURE, 0, uniq[i % 6])], flags)
+    n = 40
+    acc, noz = {5, 17, 33}, {2, 17, 39}
+    fr = [wide(i, (0 if i in acc else abi.FUSED_CLEAR) | (abi.NO_Z_READBACK if i in noz else 0)) for i in range(n)]
+    planes = np.zeros((n, 4, H, W), np.float32)
+    planes[:, 0] = np.inf
+    for i in acc:
+        planes[i, 0, 200:260] = 2.0 + i
+        planes[i, 1:4, 200:260] = 11.0 + i
+    init = planes.copy()
+    ctx.host_register(planes)
+    try:
+        got, _ = ctx.draw_batch(fr, planes)
+        for i, f in enumerate(fr):
+            rc, ref, _ = orc.draw(wide(i, f.c.flags & ~abi.NO_Z_READBACK), tuple(init[i, p].copy() for p in range(4)) if i in acc else None)
+            assert rc == 0
+            for p in range(4):
+                want = init[i, 0] if (p == 0 and i in noz) else ref[p]
+                assert np.array_equal(bits(got[i, p]), bits(want)), (i, p)
+        # srz_draw, registered planes, no depth read-back
+        one = tuple(planes[0, p] for p in range(4))
+        one[0][:] = -5.0
+        ctx.draw(fr[2], one)
+        rc, ref, _ = orc.draw(wide(2, abi.FUSED_CLEAR))
+        assert (one[0] == -5.0).all() and all(np.array_equal(bits(one[p]), bits(ref[p])) for p in (1, 2, 3))
+    finally:
+        ctx.host_unregister(planes)
+    ctx.close()
+
+
 def test_undocumented_flag_bits_and_debug_environment_are_ignored(orc, frames, monkeypatch):
     """the kernel-ablation switches of the development builds are gone: neither SRZ_DEBUG_FLAGS nor stray high flag bits
     change a render"""

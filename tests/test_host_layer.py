@@ -106,7 +106,7 @@ def test_jpeg_decoder_live_against_pillow(tmp_path):
 def test_jpeg_decoder_rejects_what_it_does_not_decode(tmp_path):
     """truncated files, a frame header of an unsupported process (arithmetic coding, 12-bit, CMYK), garbage after SOI and corrupt
     tables raise the loader's error (an empty cv::Mat in the reference → its runtime_error), they do not crash the host process
-    (one-off: 18 000 mutated files through an AddressSanitizer + UBSan build of image_io.cpp + jpeg_decode.cpp, 10 000 mutated PNGs)"""
+    (the sanitizer side of this is tests/test_host_fuzz.py: seeded mutations of the fixtures through an AddressSanitizer + UBSan build)"""
     good = open(os.path.join(REPO, "tests", "golden", "jpeg", "base_444_64.jpg"), "rb").read()
     sof = good.index(b"\xff\xc0")
     cases = {"no_frame": good[:sof], "arith": good[:sof] + b"\xff\xc9" + good[sof + 2:], "bits12": good[:sof + 4] + b"\x0c" + good[sof + 5:],
