@@ -41,7 +41,7 @@ extern "C" {
  *   5  srz_set_option, srz_verify_fastpow; srz_frameset_gathered_row_offset returns (size_t)-1 for an unknown `what` too
  *   6  SRZ_OPT_APPROX_SHADE (the tolerance mode of the shaders); srz_frameset_resolve8 / _deinterleave / the bgr8 exchange take any width;
  *      the tile-list pool is sized by srz_frameset_create / srz_sceneset_create, the first srz_frameset_render no longer blocks
- *   7  srz_host_register / srz_host_unregister, SRZ_NO_Z_READBACK, srz_verify_fastlen; srz_draw_batch reads one piece of the batch
+ *   7  srz_host_register / srz_host_unregister, SRZ_NO_Z_READBACK, srz_verify_fastlen, srz_frameset_debug_counters; srz_draw_batch reads one piece of the batch
  *      back while the next one renders
  */
 #define SRZ_ABI_VERSION 7
@@ -343,6 +343,9 @@ int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4);
  * out5 = { pairs, results that differ although the flag was clear (must be 0), flagged random pairs, flagged Pythagorean pairs,
  * flagged few-significant-bit pairs }. */
 int srz_verify_fastlen(srz_ctx *ctx, uint64_t *out5);
+/* diagnostic only (tests): counters the LAST render of the set left — out4 = { tiles taken by the ordered rasteriser, tiles the FAST
+ * shading builds handed to the generic build, capacity of a tile-list sub-pool, largest demand a sub-pool reported }; waits for the device */
+int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out4);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);
 

@@ -164,8 +164,10 @@ def draw_frames_omp(frames, n_total, threads=0, fast=False):
 
 def debug_s(mode):
     """test probe: 0 = the reference's result; 1 = scalar-tail pixels keep the value in front of the truncation; 2 = scalar-tail
-    pixels are written as -1 (a class marker).  Only the -O2 checker build; reset it to 0 when done."""
-    lib().orc_debug_s(int(mode))
+    pixels are written as -1 (a class marker).  Only the -O2 checker build has the probe compiled in (-DORC_TEST_PROBES: the -O3
+    baseline build's hot loop is free of it); reset it to 0 when done."""
+    if lib().orc_debug_s(int(mode)) != 0:
+        raise RuntimeError("the oracle build in use was compiled without ORC_TEST_PROBES")
 
 
 def resolve8(planes):

@@ -145,6 +145,7 @@ struct srz_frameset {
   uint64_t sdesc_version = 0;
   uint32_t tiles_x = 0, max_tiles = 0;
   bool have_stats = false;
+  bool update_failed = false; // an update re-classified the frames but could not get the work lists they need: renders are refused
   srz_stats stats{};
 };
 
@@ -235,19 +236,22 @@ uint32_t kinds_needed(const srz_frameset *fs) {
 hipError_t ensure_worklists(srz_frameset *fs) {
   const uint32_t need = kinds_needed(fs) | fs->kind_mask;
   if (need == fs->kind_mask && fs->d_worklist) return hipSuccess;
-  if (fs->d_worklist) { // renders in flight may still be walking the old lists
-    (void)hipDeviceSynchronize();
-    (void)hipFree(fs->d_worklist);
-    fs->d_worklist = nullptr;
-  }
   uint64_t slots = 0;
   uint32_t n = 0;
   for (uint32_t k = 0; k <= SHADE_KIND_GENERIC; ++k)
     if (need & (1u << k)) slots |= (uint64_t)(n++) << (4u * k);
   const size_t cap = (size_t)(fs->n_frames < 8 ? fs->n_frames : (fs->n_frames + 7) / 8) * fs->n_local_bands * fs->tiles_x;
-  const hipError_t e = hipMalloc((void **)&fs->d_worklist, std::max<size_t>(sizeof(uint4) * 8u * n * cap, 256));
-  if (e == hipSuccess) fs->kind_mask = need, fs->kind_slots = slots, fs->n_kind_slots = n;
-  return e;
+  // the new storage first, the swap only on success: a failed allocation leaves the set exactly as it was (old lists, old slots) —
+  // callers that had already re-classified the frames for a kind without a slot roll that back (srz_sceneset_update, srz_draw)
+  uint4 *nw = nullptr;
+  const hipError_t e = hipMalloc((void **)&nw, std::max<size_t>(sizeof(uint4) * 8u * n * cap, 256));
+  if (e != hipSuccess) return e;
+  if (fs->d_worklist) { // renders in flight may still be walking the old lists
+    (void)hipDeviceSynchronize();
+    (void)hipFree(fs->d_worklist);
+  }
+  fs->d_worklist = nw, fs->kind_mask = need, fs->kind_slots = slots, fs->n_kind_slots = n;
+  return hipSuccess;
 }
 
 void free_frameset_buffers(srz_frameset *fs) {
@@ -378,6 +382,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
                 bool size_only = false, int f_begin = 0, int f_count = -1) {
   if (fs->shard_rank != ctx->shard_rank || fs->shard_world != ctx->shard_world)
     return fail(ctx, SRZ_E_INVALID, "frameset was created under a different shard (call srz_set_shard before srz_frameset_create)");
+  if (fs->update_failed) return fail(ctx, SRZ_E_NOMEM, "the last update of this set failed (out of memory): update it again or destroy it");
   for (const BatchDesc &b : fs->h_batches) {
     if (size_only) break;
     bool needs = b.shader == SRZ_SHADER_TEXTURE || b.shader == SRZ_SHADER_DISPLACEMENT || b.shader == SRZ_SHADER_BUMP;
@@ -914,7 +919,13 @@ int srz_mesh_upload(srz_ctx *ctx, int mesh_id, const srz_vertex *verts, uint32_t
   return SRZ_OK;
 }
 
+static int sceneset_create_impl(srz_ctx *ctx, const srz_scene_frame *frames, int n_frames, srz_frameset **out, bool size_pool);
 int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frames, srz_frameset **out) {
+  return sceneset_create_impl(ctx, frames, n_frames, out, /*size_pool=*/true);
+}
+// (size_pool = false: srz_draw_scene's internal one-frame set — rendered at once, its first render sizes the pool: no second binning
+// pass, no extra synchronisation per signature change)
+static int sceneset_create_impl(srz_ctx *ctx, const srz_scene_frame *frames, int n_frames, srz_frameset **out, bool size_pool) {
   if (!ctx) return SRZ_E_INVALID;
   if (!out) return fail(ctx, SRZ_E_INVALID, "srz_sceneset_create: out is NULL");
   *out = nullptr;
@@ -990,7 +1001,7 @@ int srz_sceneset_create(srz_ctx *ctx, const srz_scene_frame *frames, int n_frame
   fs->d_lights = reinterpret_cast<srz_light *>(blk + fs->dyn_lights_off);
   fs->d_draws = reinterpret_cast<DrawDesc *>(blk + fs->dyn_draws_off);
   *out = fs;
-  return size_pool_at_create(ctx, out); // (with the matrices of creation: a later srz_sceneset_update is followed by the lazy growth)
+  return size_pool ? size_pool_at_create(ctx, out) : SRZ_OK; // (with the matrices of creation: a later srz_sceneset_update is followed by the lazy growth)
 }
 
 int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *frames, int n_frames) {
@@ -1024,7 +1035,10 @@ int srz_sceneset_update(srz_ctx *ctx, srz_frameset *fs, const srz_scene_frame *f
     }
   }
   classify_frames(fs, h_lights.data());
-  if (ensure_worklists(fs) != hipSuccess) return fail(ctx, SRZ_E_NOMEM, "srz_sceneset_update: hipMalloc of the work lists failed");
+  // (the host copies of the descriptors are re-classified by now: if the lists for a new build kind cannot be had, the set stays
+  // refused by render_impl until an update succeeds — its old lists are intact, but its frames no longer match them)
+  fs->update_failed = ensure_worklists(fs) != hipSuccess;
+  if (fs->update_failed) return fail(ctx, SRZ_E_NOMEM, "srz_sceneset_update: hipMalloc of the work lists failed");
   // one asynchronous copy on the context's stream: ordered after every render already submitted there (which may still
   // be reading the descriptors) and before the next one.  Renders submitted on OTHER streams are the caller's to order.
   const unsigned slot = fs->stage_next++ % srz_frameset::STAGE_RING;
@@ -1294,6 +1308,24 @@ int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4) {
   return SRZ_OK;
 }
 
+/* diagnostic (tests): what the LAST render of the set left in its counters — out4 = { tiles the ordered rasteriser (k_raster_slow)
+ * took, tiles the FAST shading builds handed to the generic one, the tile-list pool's capacity per sub-pool, the largest demand a
+ * sub-pool has reported }.  Waits for the device. */
+int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out4) {
+  if (!ctx || !fs || !out4) return ctx ? fail(ctx, SRZ_E_INVALID, "srz_frameset_debug_counters: null argument") : SRZ_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  uint32_t h[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpy(h, fs->d_slow_count, sizeof h, hipMemcpyDeviceToHost));
+  uint32_t need = 0;
+  for (uint32_t i = 0; i < fs->pool_n_sub * (uint32_t)srz_frameset::DEMAND_PARTS; ++i) {
+    const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[((i / fs->pool_n_sub) * 64u + i % fs->pool_n_sub) * CNT_STRIDE];
+    if (v > need) need = v;
+  }
+  out4[0] = h[0], out4[1] = h[1], out4[2] = fs->pool_sub_cap, out4[3] = need;
+  return SRZ_OK;
+}
+
 int srz_verify_fastlen(srz_ctx *ctx, uint64_t *out5) {
   if (!ctx || !out5) return SRZ_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1534,7 +1566,8 @@ static int refresh_plain_frame(srz_ctx *ctx, srz_frameset *fs, const srz_frame &
   d.flags = fr.flags & (SRZ_UNIFIED | SRZ_FUSED_CLEAR | SRZ_ORDERED_RASTER);
   if (fr.n_lights != d.n_lights || (fr.n_lights && !fr.lights)) return fail(ctx, SRZ_E_INVALID, "srz_draw: light count changed");
   classify_frames(fs, fr.lights, /*one_frame=*/true);
-  if (ensure_worklists(fs) != hipSuccess) return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc of the work lists failed");
+  fs->update_failed = ensure_worklists(fs) != hipSuccess; // (see srz_sceneset_update)
+  if (fs->update_failed) return fail(ctx, SRZ_E_NOMEM, "srz_draw: hipMalloc of the work lists failed");
   HIP_TRY(ctx, hipMemcpyAsync(fs->d_frames, fs->h_frames.data(), sizeof(FrameDesc), hipMemcpyHostToDevice, s));
   if (fr.n_lights) HIP_TRY(ctx, hipMemcpyAsync(fs->d_lights, fr.lights, sizeof(srz_light) * fr.n_lights, hipMemcpyHostToDevice, s));
   size_t o = 0;
@@ -1580,7 +1613,7 @@ static int draw_impl(srz_ctx *ctx, int primitive, const srz_frame *frame, const 
     if (ctx->draw_fs) srz_frameset_destroy(ctx, ctx->draw_fs);
     (void)hipFree(ctx->draw_out);
     ctx->draw_fs = nullptr, ctx->draw_out = nullptr, ctx->draw_sig.clear();
-    rc = frame ? build_frameset(ctx, frame, 1, &ctx->draw_fs, true, /*tris_aos=*/true) : srz_sceneset_create(ctx, scene, 1, &ctx->draw_fs);
+    rc = frame ? build_frameset(ctx, frame, 1, &ctx->draw_fs, true, /*tris_aos=*/true) : sceneset_create_impl(ctx, scene, 1, &ctx->draw_fs, false);
     if (rc) return rc;
     if (hipMalloc(&ctx->draw_out, 4 * (size_t)W * H * sizeof(float)) != hipSuccess) {
       srz_frameset_destroy(ctx, ctx->draw_fs);

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = ["srz_abi_version", "srz_create", "srz_destroy", "srz_last_error", "srz_set_shard", "srz_set_option", "srz_texture_upload",
            "srz_draw", "srz_draw_scene", "srz_mesh_upload", "srz_sceneset_create", "srz_frameset_create", "srz_frameset_destroy", "srz_frameset_local_rows",
            "srz_frameset_out_bytes", "srz_frameset_render", "srz_frameset_resolve8", "srz_frameset_stats", "srz_frameset_algorithmic_bytes",
-           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_verify_fastpow", "srz_verify_fastlen", "srz_host_register", "srz_host_unregister", "srz_draw_batch",
+           "srz_kernel_time_ms", "srz_kernel_time_samples", "srz_set_kernel_timing", "srz_sync", "srz_debug_counters", "srz_verify_fastmath", "srz_verify_fastdiv", "srz_verify_fastpow", "srz_verify_fastlen", "srz_host_register", "srz_host_unregister", "srz_frameset_debug_counters", "srz_draw_batch",
            "srz_comm_unique_id", "srz_comm_create", "srz_comm_destroy", "srz_frameset_exchange_bytes", "srz_frameset_allgather",
            "srz_frameset_deinterleave", "srz_frameset_allgather_inplace", "srz_frameset_gathered_row_offset",
            "srz_frameset_read_gathered_frame"]
@@ -80,6 +80,7 @@ def lib():
         L.srz_verify_fastlen.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.srz_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]
         L.srz_host_unregister.argtypes = [vp, C.c_void_p]
+        L.srz_frameset_debug_counters.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         L.srz_comm_unique_id.argtypes = [vp]
         L.srz_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.srz_comm_destroy.argtypes = [vp, vp]
@@ -137,6 +138,12 @@ class FrameSet:
         """display()'s 8-bit resolve on the device: planes (render output) → [frame][rows][W][3] uint8."""
         self.ctx._check(lib().srz_frameset_resolve8(self.ctx.h, self.h, C.c_void_p(d_planes_ptr), C.c_void_p(d_bgr8_ptr), bgr8_bytes,
                                                     _stream(stream)))
+
+    def debug_counters(self):
+        """(tests) what the last render left: {slow_tiles, redo_tiles, pool_sub_cap, pool_demand}; waits for the device"""
+        out = (C.c_uint32 * 4)()
+        self.ctx._check(lib().srz_frameset_debug_counters(self.ctx.h, self.h, out))
+        return dict(zip(("slow_tiles", "redo_tiles", "pool_sub_cap", "pool_demand"), (int(x) for x in out)))
 
     def exchange_bytes(self, what=abi.EXCHANGE_PLANES):
         return int(lib().srz_frameset_exchange_bytes(self.ctx.h, self.h, what))

@@ -121,16 +121,21 @@ def test_pool_overflow_then_growth(ctx, orc, monkeypatch):
             t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
         nn = rng.normal(size=(n, 3, 3))
         t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
-        f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
-        rc, ref, _ = orc.draw(f)
-        assert rc == 0
+        # (eye behind the triangles' winding: none of them is culled — with test_oracle_kat.frame's default eye every one was, and
+        # rounds 2-5 ran this test on an empty frame)
+        f = frame(t, w, h, shader=abi.SHADER_NORMAL, eye=(0, 0, -1), flags=abi.FUSED_CLEAR)
+        rc, ref, st = orc.draw(f)
+        assert rc == 0 and st["n_culled"] == 0 and st["visible"] > 500000, st
         fs = ctx.frameset([f])
         out = torch.zeros(fs.out_shape, dtype=torch.float32, device="cuda")
+        slow = []
         for it in range(3):
             out.fill_(-1.0)
             fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             same(out[0].cpu().numpy(), ref, f"pool overflow, render {it}")
+            slow.append(fs.debug_counters()["slow_tiles"])
+        assert slow[0] > 0 and slow[-1] == 0, slow     # the first render's overflowing bands went the ordered way, the last one's none
         fs.close()
     finally:
         ctx.set_option(abi.OPT_POOL_LAZY, 0)
@@ -151,15 +156,19 @@ def test_pool_is_sized_when_the_set_is_created(orc):
         t["pos"][i] = [[-40 + 3 * i, -30, 10 + i % 5], [w + 50 - i, 10 + 2 * i, 12 + (i * 7) % 5], [200 + 5 * i, h + 60, 11 + (i * 3) % 7]]
     nn = rng.normal(size=(n, 3, 3))
     t["nrm"] = nn / np.linalg.norm(nn, axis=2, keepdims=True)
-    f = frame(t, w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
-    rc, ref, _ = orc.draw(f)
-    assert rc == 0
+    f = frame(t, w, h, shader=abi.SHADER_NORMAL, eye=(0, 0, -1), flags=abi.FUSED_CLEAR)
+    rc, ref, st = orc.draw(f)
+    assert rc == 0 and st["n_culled"] == 0 and st["visible"] > 500000, st
     for (rank, world) in ((0, 1), (1, 2)):
         c = srz.Context(0, rank, world)
         fs = c.frameset([f, f])
         out = torch.full(fs.out_shape, -1.0, dtype=torch.float32, device="cuda")
         fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
+        # the FIRST render took the fast path everywhere: no band overflowed the pool creation sized (the ordered rasteriser would
+        # give the same pixels, so the pixels alone do not prove it)
+        dc = fs.debug_counters()
+        assert dc["slow_tiles"] == 0 and dc["pool_sub_cap"] >= dc["pool_demand"] > 0, dc
         got = out.cpu().numpy()
         if world == 1:
             same(got[0], ref, "sized at creation, first render")

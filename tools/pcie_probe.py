@@ -1,6 +1,8 @@
 """dev tool: the PCIe-inclusive rate of the boundary's host-buffer entry points (srz_draw: planes in / out as host memory) against the
 device-resident frameset path — config 2 (spot TEXTURE 1024^2)"""
 import time
+import torch  # (first: its bundled HIP runtime must initialise the device before libsrz.so's does)
+torch.cuda.init()
 import conftest  # noqa: F401
 import numpy as np
 import scenes
