@@ -1602,9 +1602,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
 
   // ---- phase B: the tile's list, 64 records at a time --------------------------------------------------------------
   // geometry of one record's bbox ∩ tile in TILE-LOCAL coordinates: V columns [x0, v-1] in nseg pieces of 8, S columns [v, x1]
+  // An S item is a COLUMN piece: S_ROWS vertically adjacent pixels of one scalar-tail column.  (Rounds 2-5: one pixel per item —
+  // 45 instructions of item expansion per pixel test; a triangle's S columns are at most 7 wide but as tall as its box, so pieces
+  // run down the column: the x-dependent halves of the three edge functions are shared by the piece's pixels.)
+  constexpr uint32_t S_ROWS = 4;
   struct Geo {
     bool ok;
-    uint32_t nV, nS, word; // items of the two kinds; packed x0 | y0 << 5 | v << 10 | nseg << 16 | ws << 19
+    uint32_t nV, nS, word; // items of the two kinds; packed x0 | y0 << 5 | v << 10 | nseg << 16 | ws << 19 | (rows - 1) << 22
     float zmin;            // nearest vertex depth
   };
   auto geometry = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, float s_area, bool valid) {
@@ -1633,8 +1637,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     Geo g;
     g.ok = valid && x0 <= x1 && y0 <= y1;
     const uint32_t h = g.ok ? (uint32_t)(y1 - y0 + 1) : 0u, nseg = (uint32_t)(v - x0 + 7) >> 3, ws = (uint32_t)(x1 + 1 - v);
-    g.nV = __umul24(h, nseg), g.nS = __umul24(h, ws); // <= 128 / <= 224 per triangle
-    g.word = (uint32_t)x0 | ((uint32_t)y0 << 5) | ((uint32_t)v << 10) | (nseg << 16) | (ws << 19);
+    g.nV = __umul24(h, nseg), g.nS = __umul24((h + S_ROWS - 1u) / S_ROWS, ws); // <= 128 / <= 56 per triangle
+    g.word = (uint32_t)x0 | ((uint32_t)y0 << 5) | ((uint32_t)v << 10) | (nseg << 16) | (ws << 19) | (((h - 1u) & 31u) << 22);
     g.zmin = __builtin_fminf(__builtin_fminf(r0.z, r1.y), r2.x);
     return g;
   };
@@ -1689,7 +1693,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     const Geo G = geometry(r0, r1, r2, rec_s_area, valid);
     const uint32_t geom = G.word;
     uint32_t group = 0, n_groups = 1, znear = 0, znear_s = 0; // nearest possible depth of a V / S fragment, as keys (0: unknown → kept)
-    if ((uint32_t)rl_i((int)wave_scan_add(8u * G.nV + G.nS), 63) > 4u * TILE * TILE) { // > 4 pixel tests per pixel of the tile
+    if ((uint32_t)rl_i((int)wave_scan_add(8u * G.nV + S_ROWS * G.nS), 63) > 4u * TILE * TILE) { // > 4 pixel tests per pixel of the tile
       float lo = G.ok ? G.zmin : __builtin_inff(), hi = G.ok ? G.zmin : -__builtin_inff();
       for (int o = 32; o > 0; o >>= 1) lo = __builtin_fminf(lo, __shfl_xor(lo, o)), hi = __builtin_fmaxf(hi, __shfl_xor(hi, o));
       if (hi > lo && hi < __builtin_inff() && lo > -__builtin_inff()) {
@@ -1765,7 +1769,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
         if (inside[px])
           __hip_atomic_fetch_min(kp + px, ((unsigned long long)zk[px] << 32) | tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // ---- S items: one pixel each (insideTriangle + barycentric(scalar) + z, src/Rasterizer.cpp:11-70,465-477) --------
+    // ---- S items: S_ROWS pixels of one column each (insideTriangle + barycentric(scalar) + z, src/Rasterizer.cpp:11-70,465-477)
     carry = 0;
     for (uint32_t P0 = 64u * (uint32_t)wave; P0 < TS; P0 += 64u * WAVES) {
       if constexpr (WAVES > 1) {
@@ -1786,22 +1790,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       const float z2 = bperm_f(src, r2.x), s_area = bperm_f(src, rec_s_area);
       const uint32_t g = bperm_u(src, geom), idx = bperm_u(src, my_idx), o = bperm_u(src, offs);
       const uint32_t item = P0 + (uint32_t)lane, i = item - (o >> 16), w = (g >> 19) & 7u;
-      const uint32_t row = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w)), col = i - __umul24(row, w);
-      const uint32_t yl = ((g >> 5) & 31u) + row, xl = ((g >> 10) & 63u) + col;
-      const float fy = (float)(ty0 + (int)yl), fx = (float)(tx0 + (int)xl);
+      const uint32_t piece = (uint32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)w)), col = i - __umul24(piece, w);
+      const uint32_t yl0 = ((g >> 5) & 31u) + S_ROWS * piece, xl = ((g >> 10) & 63u) + col;
+      const int lim = item < TS ? (int)((g >> 22) & 31u) + 1 - (int)(S_ROWS * piece) : 0; // rows of this piece inside the rectangle
+      const float fy0 = (float)(ty0 + (int)yl0), fx = (float)(tx0 + (int)xl);
+      // the reference's expressions per pixel; what depends on x alone is the same for the piece's pixels.  P?x = ?x - fx is the exact
+      // negative of ?Px = fx - ?x, and a product of two negated factors is the product: aPBC = PBx * PCy - PBy * PCx = BPx * CPy - BPy * CPx
       const float ABx = bx - ax, ABy = by - ay, BCx = cx - bx, BCy = cy - by, CAx = ax - cx, CAy = ay - cy;
-      const float APx = fx - ax, APy = fy - ay, BPx = fx - bx, BPy = fy - by, CPx = fx - cx, CPy = fy - cy;
-      const float e0 = ABx * APy - ABy * APx, e1 = BCx * BPy - BCy * BPx, e2 = CAx * CPy - CAy * CPx;
-      const bool in_tri = ((e0 > 0) & (e1 > 0) & (e2 > 0)) | ((e0 < 0) & (e1 < 0) & (e2 < 0));
-      const float PAx = ax - fx, PAy = ay - fy, PBx = bx - fx, PBy = by - fy, PCx = cx - fx, PCy = cy - fy;
-      const float aPBC = PBx * PCy - PBy * PCx, aPCA = PCx * PAy - PCy * PAx;
-      const float al = aPBC / s_area, be = aPCA / s_area, ga = 1.0f - al - be;
-      const float z = al * z0 + be * z1 + ga * z2;
-      if ((item < TS) & in_tri) { // '<=' passes and so does a NaN depth (src/Rasterizer.cpp:475): key 0 = "ask the ordered rasteriser"
-        const uint32_t zk = (z == z) ? zkey_of(z) : 0u;
-        __hip_atomic_fetch_min(s_key + ((yl << 5) + yl) + xl, ((unsigned long long)zk << 32) | (0x7ffffffeu - idx), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      const float APx = fx - ax, BPx = fx - bx, CPx = fx - cx;
+      const float t0 = ABy * APx, t1 = BCy * BPx, t2 = CAy * CPx;
+      unsigned long long *kp = s_key + ((yl0 << 5) + yl0) + xl; // yl0 * KEY_STRIDE; the next row is KEY_STRIDE keys further
+      const uint32_t tb = 0x7ffffffeu - idx;
+      uint32_t zk[S_ROWS];
+      bool hit[S_ROWS];
+#pragma unroll
+      for (int k = 0; k < (int)S_ROWS; ++k) {
+        const float fy = fy0 + (float)k; // (exact)
+        const float APy = fy - ay, BPy = fy - by, CPy = fy - cy;
+        const float e0 = ABx * APy - t0, e1 = BCx * BPy - t1, e2 = CAx * CPy - t2;
+        const bool in_tri = ((e0 > 0) & (e1 > 0) & (e2 > 0)) | ((e0 < 0) & (e1 < 0) & (e2 < 0));
+        const float aPBC = BPx * CPy - BPy * CPx, aPCA = CPx * APy - CPy * APx;
+        const float al = aPBC / s_area, be = aPCA / s_area, ga = 1.0f - al - be;
+        const float z = al * z0 + be * z1 + ga * z2;
+        hit[k] = (k < lim) & in_tri; // '<=' passes and so does a NaN depth (src/Rasterizer.cpp:475): key 0 = "ask the ordered rasteriser"
+        zk[k] = (z == z) ? zkey_of(z) : 0u;
+        asm volatile("" : "+v"(zk[k])); // (as in the V loop: the arithmetic of the piece's pixels is one straight line)
       }
+#pragma unroll
+      for (int k = 0; k < (int)S_ROWS; ++k)
+        if (hit[k])
+          __hip_atomic_fetch_min(kp + k * KEY_STRIDE, ((unsigned long long)zk[k] << 32) | tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // the tile's farthest depth after this group (pixels outside the frame keep +inf: no dropping there); also between the
     // chunks of a long list once dropping has started paying
@@ -2132,6 +2150,19 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
 // One work item = one band of one frame, written ROW-MAJOR: a wave-instruction covers 1 KiB of one framebuffer row
 // (256 consecutive pixels), so runs of untouched tiles become long contiguous DRAM bursts instead of 128-byte tile rows
 // 4 KiB apart — the same bytes occupy the memory system for less time, which is what the kernels beside it pay for.
+// (POL: the cache policy of the clear's stores — 0 nt (shipped), 1 sc1 nt, 2 sc0 sc1 nt, 3 sc1, 4 plain: SRZ_CLEAR_POL, A/B only)
+template <int POL> __device__ __forceinline__ void store_pol(float *p, const float4 &v) {
+  if constexpr (POL == 0) {
+    store_nt(p, v);
+  } else {
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(w) : "memory");
+    if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(w) : "memory");
+    if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+    if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+  }
+}
+template <int POL>
 __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
   const uint32_t n_rows = a.n_frames * a.n_local_bands;
   const float inf = __builtin_inff();
@@ -2146,12 +2177,12 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W;
     const SRZ_CAS u32x2 *cnt = as_const(reinterpret_cast<const u32x2 *>(a.tile_info)) + (size_t)br * a.tiles_x;
-    for (int x4 = (int)threadIdx.x * 4; x4 < W; x4 += 256 * 4) {
+    for (int x4 = (int)threadIdx.x * 4; x4 < W; x4 += (int)blockDim.x * 4) {
       if (cnt[(uint32_t)x4 / TILE].x != 0u) continue; // some bbox reaches this tile: the rasteriser's
       if (((W & 3) == 0)) {
         for (int ly = 0; ly < rows; ++ly) {
           float *g = base + (size_t)ly * W + x4;
-          store_nt(g, inf4), store_nt(g + plane, zero4), store_nt(g + 2 * plane, zero4), store_nt(g + 3 * plane, zero4);
+          store_pol<POL>(g, inf4), store_pol<POL>(g + plane, zero4), store_pol<POL>(g + 2 * plane, zero4), store_pol<POL>(g + 3 * plane, zero4);
         }
       } else { // odd widths: scalar stores, the quad may end at the frame's edge or straddle nothing else (TILE % 4 == 0)
         for (int ly = 0; ly < rows; ++ly)
@@ -2874,7 +2905,17 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
   const uint32_t n_rows = a.n_frames * a.n_local_bands;
   const uint32_t cap = !beside_raster ? 2048u : (env ? env : 64u);
   (void)max_tiles;
-  hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(256), 0, s, a);
+  static const uint32_t env_thr = getenv("SRZ_CLEAR_THREADS") ? (uint32_t)atoi(getenv("SRZ_CLEAR_THREADS")) : 0u; // (A/B: 64 / 128 / 256)
+  const uint32_t thr = (beside_raster && env_thr) ? env_thr : 256u;
+  static const int pol = getenv("SRZ_CLEAR_POL") ? atoi(getenv("SRZ_CLEAR_POL")) : 0;
+  const dim3 grid(n_rows < cap ? n_rows : cap);
+  switch (beside_raster ? pol : 0) {
+  case 1: hipLaunchKernelGGL(k_clear<1>, grid, dim3(thr), 0, s, a); break;
+  case 2: hipLaunchKernelGGL(k_clear<2>, grid, dim3(thr), 0, s, a); break;
+  case 3: hipLaunchKernelGGL(k_clear<3>, grid, dim3(thr), 0, s, a); break;
+  case 4: hipLaunchKernelGGL(k_clear<4>, grid, dim3(thr), 0, s, a); break;
+  default: hipLaunchKernelGGL(k_clear<0>, grid, dim3(thr), 0, s, a); break;
+  }
 }
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, bool approx, hipStream_t s) {
