@@ -1341,6 +1341,11 @@ int srz_verify_fastlen(srz_ctx *ctx, uint64_t *out5) {
 /* diagnostic: raw counters of the last STATS run (incl. per-phase cycle sums); not part of the stable ABI */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n) {
   if (!ctx || !out) return SRZ_E_INVALID;
+#ifdef SRZ_PHASE_PROBE /* dev build: the device counters as they are now (k_shade's phase clocks), then zeroed */
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(ctx->dbg, ctx->d_stats, sizeof ctx->dbg, hipMemcpyDeviceToHost);
+  (void)hipMemset(ctx->d_stats, 0, sizeof ctx->dbg);
+#endif
   for (int i = 0; i < n && i < ST_COUNT; ++i) out[i] = ctx->dbg[i];
   return ST_COUNT;
 }

@@ -2150,19 +2150,6 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
 // One work item = one band of one frame, written ROW-MAJOR: a wave-instruction covers 1 KiB of one framebuffer row
 // (256 consecutive pixels), so runs of untouched tiles become long contiguous DRAM bursts instead of 128-byte tile rows
 // 4 KiB apart — the same bytes occupy the memory system for less time, which is what the kernels beside it pay for.
-// (POL: the cache policy of the clear's stores — 0 nt (shipped), 1 sc1 nt, 2 sc0 sc1 nt, 3 sc1, 4 plain: SRZ_CLEAR_POL, A/B only)
-template <int POL> __device__ __forceinline__ void store_pol(float *p, const float4 &v) {
-  if constexpr (POL == 0) {
-    store_nt(p, v);
-  } else {
-    f32x4 w = {v.x, v.y, v.z, v.w};
-    if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(w) : "memory");
-    if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(w) : "memory");
-    if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-    if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
-  }
-}
-template <int POL>
 __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
   const uint32_t n_rows = a.n_frames * a.n_local_bands;
   const float inf = __builtin_inff();
@@ -2182,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
       if (((W & 3) == 0)) {
         for (int ly = 0; ly < rows; ++ly) {
           float *g = base + (size_t)ly * W + x4;
-          store_pol<POL>(g, inf4), store_pol<POL>(g + plane, zero4), store_pol<POL>(g + 2 * plane, zero4), store_pol<POL>(g + 3 * plane, zero4);
+          store_nt(g, inf4), store_nt(g + plane, zero4), store_nt(g + 2 * plane, zero4), store_nt(g + 3 * plane, zero4);
         }
       } else { // odd widths: scalar stores, the quad may end at the frame's edge or straddle nothing else (TILE % 4 == 0)
         for (int ly = 0; ly < rows; ++ly)
@@ -2248,6 +2235,12 @@ void k_shade(RenderArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long n_vis = 0, n_vis_tex = 0;
+#ifdef SRZ_PHASE_PROBE /* dev build (tools/mkvariant.sh probe -DSRZ_PHASE_PROBE, tools/phase_probe.py): where a wave's time per tile goes */
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = 0;
+#define SRZ_STAMP(K) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[K] += t_ - ph_t, ph_t = t_; }
+#else
+#define SRZ_STAMP(K)
+#endif
 
   // ---- one owned tile: x = its work-list entry (work_append).  mode: 0 = FAST variants, 1 = generic (FastMath, then IEEE if
   //      needed), 2 = IEEE at once -------------------------------------------------------------------------------------------------
@@ -2258,6 +2251,9 @@ void k_shade(RenderArgs a) {
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
+#ifdef SRZ_PHASE_PROBE
+    ph_t = __builtin_amdgcn_s_memtime(), ph[5] += 1;
+#endif
     // (likewise the kernel's arguments: read from the kernarg segment per tile — scalar loads that hit the constant cache —
     // through an opaque pointer.  Loaded once at kernel entry they are ~50 scalar registers alive across everything: the compiler
     // parks them in VGPR lanes (v_writelane) and fetches them back with a VALU instruction each (v_readlane), 8 % of the
@@ -2351,6 +2347,10 @@ void k_shade(RenderArgs a) {
     *reinterpret_cast<float4 *>(&s_c[1][p0]) = C1;
     *reinterpret_cast<float4 *>(&s_c[2][p0]) = C2;
     // classify this thread's 4 pixels: per-thread counts, one packed wave scan (DPP), the waves' totals through LDS
+#ifdef SRZ_PHASE_PROBE
+    asm volatile("" : "+v"(id_raw.x), "+v"(id_raw.y), "+v"(ti[0])); // (the wait for the owner ids and the first indices lands here)
+    SRZ_STAMP(0) // tile start → owner ids + list indices here
+#endif
     uint32_t idk[4] = {id_raw.x, id_raw.y, id_raw.z, id_raw.w};
     if (by_lp) idk[0] = id_raw.x & 0xffffu, idk[1] = id_raw.x >> 16, idk[2] = id_raw.y & 0xffffu, idk[3] = id_raw.y >> 16;
     uint32_t cnt2 = 0; // V count | S count << 16 of this thread
@@ -2382,6 +2382,7 @@ void k_shade(RenderArgs a) {
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0), vmcnt / expcnt untouched
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    SRZ_STAMP(1) // → classification done, first barrier passed
     uint32_t bV = 0, bS = 0, nV = 0, nS = 0; // this wave's first slot in each list, list lengths (all wave-uniform)
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) {
@@ -2410,6 +2411,7 @@ void k_shade(RenderArgs a) {
     // for it by itself with this compiler; the explicit wait states the requirement)
     __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();
+    SRZ_STAMP(2) // → compaction done, staged triangles landed, second barrier passed
 
     // ---- 3. dense passes: the two lists are cut into 64-entry chunks dealt round-robin to the 4 waves, so a wave runs
     //         ONE shader variant per chunk with (nearly) all lanes busy; only the last chunk of each list is partial.
@@ -2554,6 +2556,7 @@ void k_shade(RenderArgs a) {
       }
     }
 
+    SRZ_STAMP(3) // → dense passes done (and the barrier behind them)
     // ---- 4. coalesced write-out of the three colour planes ----------------------------------------------------------
     if (!skip_write) {
       C0 = *reinterpret_cast<const float4 *>(&s_c[0][p0]);
@@ -2570,6 +2573,7 @@ void k_shade(RenderArgs a) {
 #undef SRZ_ST
       }
     }
+    SRZ_STAMP(4) // → write-out issued
   };
 
   // Workgroup b (on XCD b % 8) shades entries b/8, b/8 + G/8, ... of work list [this build][b % 8]: the tiles of the frames
@@ -2599,6 +2603,7 @@ void k_shade(RenderArgs a) {
       shade_tile(xc, std::integral_constant<int, 1>{});
     __syncthreads(); // LDS is reused by the next tile
   }
+
   if constexpr (!FAST) { // the tiles the FAST build handed back (it ran before this kernel on the same stream)
     const uint32_t n_redo = *as_const(a.redo_count);
     for (uint32_t i = blockIdx.x; i < n_redo; i += gridDim.x) {
@@ -2606,7 +2611,13 @@ void k_shade(RenderArgs a) {
       shade_tile(xr, std::integral_constant<int, 2>{});
       __syncthreads(); // LDS is reused by the next tile
     }
+
   }
+#ifdef SRZ_PHASE_PROBE
+  if (lane == 0 && FAST)
+    for (int k = 0; k < 6; ++k)
+      if (ph[k]) atomicAdd(&a.stats[ST_DBG_CYC_A + k], ph[k]);
+#endif
   if (STATS) {
     for (int o = 32; o > 0; o >>= 1) {
       n_vis += __shfl_down(n_vis, o);
@@ -2907,15 +2918,9 @@ void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, h
   (void)max_tiles;
   static const uint32_t env_thr = getenv("SRZ_CLEAR_THREADS") ? (uint32_t)atoi(getenv("SRZ_CLEAR_THREADS")) : 0u; // (A/B: 64 / 128 / 256)
   const uint32_t thr = (beside_raster && env_thr) ? env_thr : 256u;
-  static const int pol = getenv("SRZ_CLEAR_POL") ? atoi(getenv("SRZ_CLEAR_POL")) : 0;
-  const dim3 grid(n_rows < cap ? n_rows : cap);
-  switch (beside_raster ? pol : 0) {
-  case 1: hipLaunchKernelGGL(k_clear<1>, grid, dim3(thr), 0, s, a); break;
-  case 2: hipLaunchKernelGGL(k_clear<2>, grid, dim3(thr), 0, s, a); break;
-  case 3: hipLaunchKernelGGL(k_clear<3>, grid, dim3(thr), 0, s, a); break;
-  case 4: hipLaunchKernelGGL(k_clear<4>, grid, dim3(thr), 0, s, a); break;
-  default: hipLaunchKernelGGL(k_clear<0>, grid, dim3(thr), 0, s, a); break;
-  }
+  // (round 6, same box: the clear's stores as nt / sc1 nt / sc0 sc1 nt / sc1 / plain give config 4 3.10 / 3.22 / 3.26 / 3.29 / 3.29 ms per
+  // step and config 5 5.25 / 5.48 / 5.44 / 5.71 / 5.62: nt, as round 3 found on config 2)
+  hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(thr), 0, s, a);
 }
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, bool approx, hipStream_t s) {
