@@ -1258,6 +1258,7 @@ __device__ __forceinline__ void s_shade(M &m, const FrameK &K, const ShadeDesc &
 // list, its first index in pool[]}: everything k_shade needs to start the tile's loads travels with it, and nothing has to be
 // divided out of a flat tile number (two scalar software divisions per tile otherwise).
 constexpr uint32_t WORK_LP = 1u << 20; // the tile's owner ids are POSITIONS in the tile's triangle list, 16 bits each (see LP_BITS)
+constexpr uint32_t WORK_LP8 = 1u << 21; // (with WORK_LP, round 6) ... 8 bits each: the list has at most LP8_MAX entries (see id_pack8)
 __device__ __forceinline__ void work_append(const RenderArgs &a, uint32_t frame_flags, uint32_t frame, uint32_t entry /* frame * tiles + tile */,
                                             uint32_t lb, uint32_t tx, uint32_t wflags, uint32_t list_cnt, uint32_t list_off) {
   // (fewer than 8 frames: the tiles are dealt over the 8 lists instead, so that every XCD has work)
@@ -1283,11 +1284,18 @@ constexpr uint32_t S_CLASS_BIT = 0x80000000u;
 constexpr uint32_t PIX_SLOT = TILE * TILE, PIX_BITS = 10, PIX_MASK = PIX_SLOT - 1u;
 constexpr uint32_t LP_BITS = 9, LP_MAX = 1u << LP_BITS; // (idx << 9 | position) <= 0x7ffffffe for idx < 2^22 - 1 (FD_PACKED)
 static_assert(31 - LP_BITS == PACK_IDX_BITS, "the tie-break holds an index of PACK_IDX_BITS bits above the list position");
+// ... or, for lists of at most LP8_MAX entries (most tiles of every BASELINE config), 8 bits per pixel (position | 0x80 for the S class,
+// 0xff = nobody): the ids are written by k_raster and read back by k_shade, 1 + 1 instead of 2 + 2 bytes per pixel of every owned tile —
+// during the part of a step in which the memory system is what everything waits for (NOTEBOOK r6 §2)
+constexpr uint32_t LP8_MAX = 127;
+__device__ __forceinline__ uint32_t id_pack8(uint32_t id) { return id == NO_TRI ? 0xffu : ((id & 127u) | ((id >> 24) & 0x80u)); }
 __device__ __forceinline__ uint32_t id_pack16(uint32_t id) { return id == NO_TRI ? 0xffffu : ((id & (LP_MAX - 1u)) | ((id >> 16) & 0x8000u)); }
 __device__ __forceinline__ uint32_t id_unpack16(uint32_t h) { return h == 0xffffu ? NO_TRI : ((h & (LP_MAX - 1u)) | ((h & 0x8000u) << 16)); }
 // the four owners of pixels p0 .. p0 + 3 of a tile (p0 % 4 == 0) into / out of its slot
-__device__ __forceinline__ void ids_store4(uint32_t *slot, uint32_t p0, const uint4 &id, bool by_lp) {
-  if (by_lp) {
+__device__ __forceinline__ void ids_store4(uint32_t *slot, uint32_t p0, const uint4 &id, bool by_lp, bool lp8 = false) {
+  if (lp8) {
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(slot) + p0) = id_pack8(id.x) | (id_pack8(id.y) << 8) | (id_pack8(id.z) << 16) | (id_pack8(id.w) << 24);
+  } else if (by_lp) {
     const u32x2 w = {id_pack16(id.x) | (id_pack16(id.y) << 16), id_pack16(id.z) | (id_pack16(id.w) << 16)};
     *reinterpret_cast<u32x2 *>(reinterpret_cast<uint16_t *>(slot) + p0) = w;
   } else {
@@ -1558,6 +1566,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   const uint32_t off = tinfo.y;
   // the tie-break's payload: the triangle's index, or index << LP_BITS | its position in this tile's list (same order)
   const bool lp_mode = cnt <= LP_MAX && (fd->flags & FD_PACKED) != 0u; // wave-uniform
+  const bool lp8 = lp_mode && cnt <= LP8_MAX;                          // (the ids then take 8 bits per pixel)
   const uint32_t idx_mask = (fd->flags & FD_PACKED) ? PACK_IDX_MASK : 0xffffffffu; // (a packed list entry = index | batch << 22)
   if (off == UNLISTED || a.force_ordered || (flags & SRZ_ORDERED_RASTER)) { // the reference's ordered algorithm, from the stream
     if (lane == 0 && wave == 0) a.slow_list[atomicAdd(a.slow_count, 1u)] = frame * tiles_per_frame + tile;
@@ -1888,7 +1897,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
       const int y = ty0 + ly, x4 = tx0 + lx4;
       // the owners of ALL of the tile's pixels (those beyond the frame's edge have none: their keys never got a fragment);
       // re-read by k_shade: cacheable
-      if (tile_has_owner) ids_store4(slot, (uint32_t)(ly * TILE + lx4), id4[it], lp_mode);
+      if (tile_has_owner) ids_store4(slot, (uint32_t)(ly * TILE + lx4), id4[it], lp_mode, lp8);
       if (y > ty1 || x4 > tx1) continue;
       float *gz = out0 + (size_t)ly * W + x4;
       const bool full = vec_ok && x4 + 3 <= tx1;
@@ -1918,7 +1927,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   }
   // owned tile → the frame's own work list (a counter per frame: one shared counter serialises ~10 ns per tile)
   if (tile_has_owner && lane == 0 && wave == 0)
-    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, lb, (uint32_t)tx0 / TILE, lp_mode ? WORK_LP : 0u, cnt, off);
+    work_append(a, fd->flags, frame, frame * tiles_per_frame + tile, lb, (uint32_t)tx0 / TILE, lp_mode ? (lp8 ? WORK_LP | WORK_LP8 : WORK_LP) : 0u, cnt, off);
 }
 
 // ================================================================================================================
@@ -2264,6 +2273,7 @@ void k_shade(RenderArgs a) {
     // how the tile's ids name a pixel's owner: by position in the tile's triangle list (16-bit ids) — the list's triangles are
     // staged in LDS if they fit (by_lp && staged), else looked up per pixel (by_lp) — or by index in the frame (32-bit ids)
     const bool by_lp = (x.y & WORK_LP) != 0u, staged = by_lp && x.z <= STAGE_TRIS; // workgroup-uniform
+    const bool lp8 = (x.y & WORK_LP8) != 0u;                                        // (8-bit ids: id_pack8)
     const SRZ_CAS uint32_t *tlist = as_const(ap->pool) + x.w;
     // ---- 1. this thread's 4 pixels: their owner ids (nothing but the entry is needed for the address: the load is in flight
     //         under the frame descriptor's scalar loads), and the indices of the list entries whose pieces it will stage
@@ -2277,14 +2287,16 @@ void k_shade(RenderArgs a) {
     uint4 id_raw = make_uint4(0u, 0u, 0u, 0u);
     {
       const uint32_t *slot = ap->vis + (size_t)tile_slot * PIX_SLOT;
-      if (by_lp) {
+      if (lp8) {
+        id_raw.x = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(slot) + p0);
+      } else if (by_lp) {
         const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint16_t *>(slot) + p0);
         id_raw.x = w.x, id_raw.y = w.y;
       } else {
         id_raw = *reinterpret_cast<const uint4 *>(slot + p0);
       }
     }
-    const uint32_t none = by_lp ? 0xffffu : NO_TRI, sbit = by_lp ? 0x8000u : S_CLASS_BIT; // (scalar)
+    const uint32_t none = lp8 ? 0xffu : by_lp ? 0xffffu : NO_TRI, sbit = lp8 ? 0x80u : by_lp ? 0x8000u : S_CLASS_BIT; // (scalar)
     constexpr int PASSES = (STAGE_TRIS * 6 + 255) / 256;
     const uint32_t n_pc = staged ? x.z * 6u : 0u;
     uint32_t ti[PASSES];
@@ -2352,7 +2364,10 @@ void k_shade(RenderArgs a) {
     SRZ_STAMP(0) // tile start → owner ids + list indices here
 #endif
     uint32_t idk[4] = {id_raw.x, id_raw.y, id_raw.z, id_raw.w};
-    if (by_lp) idk[0] = id_raw.x & 0xffffu, idk[1] = id_raw.x >> 16, idk[2] = id_raw.y & 0xffffu, idk[3] = id_raw.y >> 16;
+    if (lp8)
+      idk[0] = id_raw.x & 0xffu, idk[1] = (id_raw.x >> 8) & 0xffu, idk[2] = (id_raw.x >> 16) & 0xffu, idk[3] = id_raw.x >> 24;
+    else if (by_lp)
+      idk[0] = id_raw.x & 0xffffu, idk[1] = id_raw.x >> 16, idk[2] = id_raw.y & 0xffffu, idk[3] = id_raw.y >> 16;
     uint32_t cnt2 = 0; // V count | S count << 16 of this thread
 #pragma unroll
     for (int k = 0; k < 4; ++k) cnt2 += idk[k] == none ? 0u : ((idk[k] & sbit) ? 0x10000u : 1u);
