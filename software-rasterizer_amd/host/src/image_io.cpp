@@ -137,9 +137,9 @@ static void decode_ppm(const std::vector<uint8_t> &d, const std::string &path, s
       else
         ++p;
     }
-    int v = 0;
-    while (p < d.size() && d[p] >= '0' && d[p] <= '9') v = v * 10 + (d[p++] - '0');
-    return v;
+    long v = 0; // (a run of digits that no image size can be stops growing instead of overflowing)
+    while (p < d.size() && d[p] >= '0' && d[p] <= '9') v = v < 100000000L ? v * 10 + (d[p] - '0') : v, ++p;
+    return (int)v;
   };
   W = next_int(), H = next_int();
   int mx = next_int();
@@ -147,6 +147,47 @@ static void decode_ppm(const std::vector<uint8_t> &d, const std::string &path, s
   if (W <= 0 || H <= 0 || mx != 255 || p + (size_t)W * H * 3 > d.size()) throw std::runtime_error("Cannot open file: " + path);
   bgr.resize((size_t)W * H * 3);
   for (size_t i = 0; i < (size_t)W * H; ++i) bgr[i * 3] = d[p + i * 3 + 2], bgr[i * 3 + 1] = d[p + i * 3 + 1], bgr[i * 3 + 2] = d[p + i * 3];
+}
+
+// BMP as cv::imread(path) (IMREAD_COLOR) reads it: uncompressed 8-bit palettised, 24-bit and 32-bit (alpha dropped) images with a
+// BITMAPINFOHEADER or a later header, bottom-up or top-down rows padded to four bytes.  RLE, 1 / 4 / 16-bit and OS/2 headers are refused.
+static void decode_bmp(const std::vector<uint8_t> &d, const std::string &path, std::vector<uint8_t> &bgr, int &W, int &H) {
+  auto fail = [&]() -> void { throw std::runtime_error("Cannot open file: " + path); };
+  auto le32 = [&](size_t o) { return (uint32_t)d[o] | (uint32_t)d[o + 1] << 8 | (uint32_t)d[o + 2] << 16 | (uint32_t)d[o + 3] << 24; };
+  auto le16 = [&](size_t o) { return (uint32_t)d[o] | (uint32_t)d[o + 1] << 8; };
+  if (d.size() < 54) fail();
+  const uint32_t off = le32(10), hdr = le32(14);
+  if (hdr < 40 || 14 + (size_t)hdr > d.size()) fail();
+  const int32_t w = (int32_t)le32(18), h = (int32_t)le32(22);
+  const uint32_t planes = le16(26), bpp = le16(28), comp = le32(30);
+  const bool top_down = h < 0;
+  const int64_t ah = top_down ? -(int64_t)h : (int64_t)h;
+  if (w <= 0 || ah <= 0 || w > 32768 || ah > 32768 || planes != 1 || (bpp != 8 && bpp != 24 && bpp != 32)) fail();
+  if (!(comp == 0 || (comp == 3 && bpp == 32))) fail(); // BI_RGB, or BI_BITFIELDS on 32 bits (the usual BGRA masks are assumed)
+  const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+  if (off > d.size() || stride * (size_t)ah > d.size() - off) fail();
+  uint32_t n_pal = 0;
+  const size_t pal = 14 + (size_t)hdr;
+  if (bpp == 8) {
+    n_pal = le32(46) ? le32(46) : 256u;
+    if (n_pal > 256 || pal + 4 * (size_t)n_pal > d.size()) fail();
+  }
+  W = w, H = (int)ah;
+  bgr.resize((size_t)W * H * 3);
+  for (int y = 0; y < H; ++y) {
+    const uint8_t *row = &d[off + stride * (size_t)(top_down ? y : H - 1 - y)];
+    uint8_t *o = &bgr[(size_t)y * W * 3];
+    for (int x = 0; x < W; ++x, o += 3) {
+      if (bpp == 8) {
+        const uint32_t i = row[x];
+        if (i >= n_pal) fail();
+        o[0] = d[pal + 4 * i], o[1] = d[pal + 4 * i + 1], o[2] = d[pal + 4 * i + 2];
+      } else {
+        const uint8_t *px = row + (size_t)x * (bpp / 8);
+        o[0] = px[0], o[1] = px[1], o[2] = px[2];
+      }
+    }
+  }
 }
 
 void decode_jpeg(const std::vector<uint8_t> &d, const std::string &path, std::vector<uint8_t> &bgr, int &W, int &H); // jpeg_decode.cpp
@@ -157,6 +198,8 @@ void load_image_bgr(const std::string &path, std::vector<uint8_t> &bgr, int &W, 
     decode_ppm(d, path, bgr, W, H);
   else if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8 && d[2] == 0xff)
     decode_jpeg(d, path, bgr, W, H);
+  else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M')
+    decode_bmp(d, path, bgr, W, H);
   else
     decode_png(d, path, bgr, W, H);
 }

@@ -60,6 +60,11 @@ def test_png_and_ppm_decoders_survive_mutated_files(fuzz_host, tmp_path):
         tot[0] += ok; tot[1] += rej
     ok, rej = run(fuzz_host, "png", os.path.join(REPO, "assets", "models", "Crate", "Crate1.png"), max(20, N // 20), 299, tmp_path)
     assert tot[0] > N // 2 and tot[1] > N, tot
+    for i, (name, im) in enumerate((("rgb.bmp", Image.fromarray(a[:, :, :3])), ("rgba.bmp", Image.fromarray(a)),
+                                    ("pal.bmp", Image.fromarray(a[:, :, :3]).quantize(19)))):
+        q = str(tmp_path / name)
+        im.save(q)
+        run(fuzz_host, "bmp", q, N, 250 + i, tmp_path)
     p = tmp_path / "s.ppm"
     p.write_bytes(b"P6\n# c\n17 13\n255\n" + a[:, :, :3].tobytes())
     run(fuzz_host, "ppm", str(p), N, 300, tmp_path)

@@ -261,3 +261,25 @@ def test_cpp_api_compiles_like_the_readme_and_refuses_to_run_without_a_gpu(tmp_p
         assert r.returncode == 0, r.stderr
     else:
         assert r.returncode == 3 and "no CPU fallback" in r.stderr   # constructor throws std::runtime_error
+
+
+def test_bmp_loader_equals_pillow(tmp_path):
+    """cv::imread also reads BMP (src/TextureLoader.cpp:3-12): uncompressed 24-bit, 32-bit (alpha dropped) and 8-bit palettised files,
+    odd widths (row padding), against Pillow's decode; RLE and 4-bit files are refused with the loader's error"""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    for (w, h) in ((1, 1), (5, 3), (17, 13), (64, 2)):
+        a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        for name, im in (("rgb", Image.fromarray(a[:, :, :3])), ("rgba", Image.fromarray(a)), ("pal", Image.fromarray(a[:, :, :3]).quantize(37)),
+                         ("grey", Image.fromarray(a[:, :, 0]))):
+            p = str(tmp_path / f"{name}_{w}x{h}.bmp")
+            im.save(p)
+            expect = np.asarray(Image.open(p).convert("RGB"), np.uint8)[:, :, ::-1]
+            assert np.array_equal(host.load_image_bgr(p), expect), (name, w, h)
+    good = open(str(tmp_path / "rgb_17x13.bmp"), "rb").read()
+    for name, data in (("rle", good[:30] + b"\x01" + good[31:]), ("bpp4", good[:28] + b"\x04" + good[29:]), ("short", good[:100]),
+                       ("huge", good[:18] + b"\xff\xff\xff\x7f" + good[22:])):
+        q = tmp_path / f"bad_{name}.bmp"
+        q.write_bytes(data)
+        with pytest.raises(RuntimeError):
+            host.load_image_bgr(str(q))
