@@ -2246,6 +2246,8 @@ void k_shade(RenderArgs a) {
   unsigned long long n_vis = 0, n_vis_tex = 0;
 #ifdef SRZ_PHASE_PROBE /* dev build (tools/mkvariant.sh probe -DSRZ_PHASE_PROBE, tools/phase_probe.py): where a wave's time per tile goes */
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = 0;
+  // (and the clock the wave ran at: shader clocks against the constant 100 MHz counter over the wave's whole life)
+  const unsigned long long ph_c0 = __builtin_amdgcn_s_memtime(), ph_r0 = __builtin_amdgcn_s_memrealtime();
 #define SRZ_STAMP(K) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[K] += t_ - ph_t, ph_t = t_; }
 #else
 #define SRZ_STAMP(K)
@@ -2629,9 +2631,11 @@ void k_shade(RenderArgs a) {
 
   }
 #ifdef SRZ_PHASE_PROBE
-  if (lane == 0 && FAST)
+  if (lane == 0 && FAST) {
     for (int k = 0; k < 6; ++k)
       if (ph[k]) atomicAdd(&a.stats[ST_DBG_CYC_A + k], ph[k]);
+    atomicAdd(&a.stats[0], __builtin_amdgcn_s_memtime() - ph_c0), atomicAdd(&a.stats[1], __builtin_amdgcn_s_memrealtime() - ph_r0);
+  }
 #endif
   if (STATS) {
     for (int o = 32; o > 0; o >>= 1) {

@@ -30,6 +30,7 @@ ph = c[-6:]
 tiles = ph[5] or 1
 tot = sum(ph[:5])
 names = ["ids+indices wait", "classify+barrier1", "compact+DMA+barrier2", "dense passes", "write-out issue"]
-print(f"config {cfg}, {F} frames: {tiles / n / 4:.0f} tiles per render, {tot / tiles:.0f} clocks per wave-tile")
+print(f"config {cfg}, {F} frames: {tiles / n / 4:.0f} tiles per render, {tot / tiles:.0f} clocks per wave-tile; "
+      f"k_shade's waves ran at {c[0] / max(c[1], 1) * 100:.0f} MHz (s_memtime / s_memrealtime x 100 MHz)")
 for k in range(5):
     print(f"  {names[k]:22s} {ph[k] / tiles:8.0f} clocks  {100 * ph[k] / tot:5.1f} %")
