@@ -16,7 +16,7 @@
  *     (src/Rasterizer.cpp:185-189).
  *   - the caller owns every host pointer; the library copies in/out and keeps only device state.
  *   - one ctx per host thread, one GPU per ctx, one process per GPU (multi-GPU = one ctx per rank,
- *     bands of 32 rows dealt round-robin with srz_set_shard, reassembled by an RCCL all-gather).
+ *     bands of 32 rows dealt round-robin (each round of N rotated by five ranks) with srz_set_shard, reassembled by an RCCL all-gather).
  *   - there is NO CPU fallback: every compute entry point fails with SRZ_E_NODEVICE when no
  *     gfx950 device is usable.
  */

@@ -177,7 +177,9 @@ int fail(srz_ctx *ctx, int code, const std::string &msg) {
 void shard_layout(int height, int rank, int world, uint32_t &n_bands, uint32_t &n_local, uint32_t &per_rank,
                   uint32_t &local_rows) {
   n_bands = (uint32_t)((height + BAND - 1) / BAND);
-  n_local = (uint32_t)rank < n_bands ? (n_bands - (uint32_t)rank + (uint32_t)world - 1) / (uint32_t)world : 0;
+  // (one band of every full group of `world` bands, and of the last, partial group if the rotation puts this rank inside it: band_of)
+  n_local = n_bands / (uint32_t)world;
+  if ((uint32_t)band_of((int)n_local, rank, world) < n_bands) ++n_local;
   per_rank = (n_bands + (uint32_t)world - 1) / (uint32_t)world;
   local_rows = world == 1 ? (uint32_t)height : per_rank * BAND;
 }
@@ -1215,7 +1217,7 @@ uint64_t srz_frameset_algorithmic_bytes(const srz_ctx *ctx, const srz_frameset *
   // rows actually owned (not the all-gather padding)
   uint64_t rows = 0;
   for (uint32_t lb = 0; lb < fs->n_local_bands; ++lb) {
-    int band = (int)lb * fs->shard_world + fs->shard_rank;
+    int band = band_of((int)lb, fs->shard_rank, fs->shard_world);
     rows += (uint64_t)std::min(BAND, fs->height - band * BAND);
   }
   uint64_t fb = 16ull * (uint64_t)fs->width * rows * (uint64_t)fs->n_frames;
@@ -1505,7 +1507,7 @@ size_t srz_frameset_gathered_row_offset(const srz_ctx *ctx, const srz_frameset *
   if (plane < 0 || (size_t)plane >= planes) return (size_t)-1;
   const size_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (size_t)fs->width * 3u : (size_t)fs->width * sizeof(float);
   const size_t band = (size_t)row / BAND, world = (size_t)fs->shard_world;
-  const size_t rank = band % world, local_row = (band / world) * BAND + (size_t)row % BAND;
+  const size_t rank = (size_t)rank_of_band((int)band, (int)world), local_row = (band / world) * BAND + (size_t)row % BAND;
   const size_t shard_rows = fs->shard_world == 1 ? (size_t)fs->height : (size_t)fs->bands_per_rank * BAND;
   return (((rank * (size_t)fs->n_frames + (size_t)frame) * planes + (size_t)plane) * shard_rows + local_row) * row_bytes;
 }
@@ -1521,20 +1523,14 @@ int srz_frameset_read_gathered_frame(srz_ctx *ctx, const srz_frameset *fs, const
   const size_t row_bytes = what == SRZ_EXCHANGE_BGR8 ? (size_t)fs->width * 3u : (size_t)fs->width * sizeof(float);
   const size_t band_bytes = row_bytes * BAND, world = (size_t)fs->shard_world;
   const size_t n_bands = ((size_t)fs->height + BAND - 1) / BAND;
-  // per (rank, plane): that rank's bands of the plane are consecutive in its shard and world bands apart in the host image —
-  // ONE strided copy (the last band of a frame whose height is not a multiple of 32 is copied on its own: it is short)
+  // band by band (a rank's bands are consecutive in its shard but, with the rotated band → rank map, not equidistant in the image)
+  (void)band_bytes, (void)world;
   for (size_t p = 0; p < planes; ++p)
-    for (size_t r = 0; r < world && r < n_bands; ++r) {
-      const size_t n_local = (n_bands - r + world - 1) / world;
-      const size_t last_band = r + (n_local - 1) * world;
-      const size_t last_rows = std::min<size_t>(BAND, (size_t)fs->height - last_band * BAND); // (short only for the frame's last band)
-      const size_t full_bands = last_rows == BAND ? n_local : n_local - 1;
-      const uint8_t *src = static_cast<const uint8_t *>(d_gathered) + srz_frameset_gathered_row_offset(ctx, fs, what, frame, (int)p, (int)(r * BAND));
-      uint8_t *dst = static_cast<uint8_t *>(host_out) + (p * (size_t)fs->height + r * BAND) * row_bytes;
-      if (full_bands)
-        HIP_TRY(ctx, hipMemcpy2DAsync(dst, world * band_bytes, src, band_bytes, band_bytes, full_bands, hipMemcpyDeviceToHost, s));
-      if (full_bands < n_local)
-        HIP_TRY(ctx, hipMemcpyAsync(dst + full_bands * world * band_bytes, src + full_bands * band_bytes, last_rows * row_bytes, hipMemcpyDeviceToHost, s));
+    for (size_t b = 0; b < n_bands; ++b) {
+      const size_t rows = std::min<size_t>(BAND, (size_t)fs->height - b * BAND);
+      const uint8_t *src = static_cast<const uint8_t *>(d_gathered) + srz_frameset_gathered_row_offset(ctx, fs, what, frame, (int)p, (int)(b * BAND));
+      uint8_t *dst = static_cast<uint8_t *>(host_out) + (p * (size_t)fs->height + b * BAND) * row_bytes;
+      HIP_TRY(ctx, hipMemcpyAsync(dst, src, rows * row_bytes, hipMemcpyDeviceToHost, s));
     }
   HIP_TRY(ctx, hipStreamSynchronize(s));
   return SRZ_OK;

@@ -17,6 +17,25 @@ constexpr int BAND = 32;             // band = one row of tiles; the unit of mul
 constexpr int KEY_STRIDE = TILE + 1;
 // LDS row stride (dwords) of the ORDERED rasteriser's z / owner planes (k_raster_slow)
 constexpr int LDS_STRIDE = 32;
+// ---- which rank owns which 32-row band (round 6) ----------------------------------------------------------------------------------
+// Every group g = b / world of `world` consecutive bands hands ONE band to every rank, ROTATED by BAND_ROT steps per group:
+//     rank(b) = (b + BAND_ROT * (b / world)) % world,   local band index = b / world,
+//     band(lb, rank) = lb * world + (rank - BAND_ROT * lb) mod world.
+// (Rounds 1-5: rank = b % world.  A scene whose period in bands is a multiple of `world` — config 4's four rows of cows, 16 bands each,
+// on 8 ranks — then gave rank r the SAME two slices of every cow: per-rank render times 1.19-1.21 x their mean.  With a rotation a rank
+// meets a different slice in every group.  Measured with one GPU playing every rank of 8 (bench.py emulate_shards, max / mean of the
+// per-rank render times, configs 2 / 4 / 5): no rotation 1.05-1.06 / 1.19-1.21 / 1.02-1.04; 1 step 1.15 / 1.07-1.09 / 1.02-1.04; 3 steps
+// 1.12 / 1.09 / 1.02; 5 steps 1.06 / 1.09 / 1.04 — five it is (one step where five is a multiple of the world).  Buffers, local indices
+// and the exchange are unchanged: the gathered layout is still [rank][frame][plane][local band][32 rows].)
+#ifndef SRZ_BAND_ROT
+#define SRZ_BAND_ROT 5 /* (A/B builds: 0 = the plain b % world of rounds 1-5) */
+#endif
+__host__ __device__ inline int band_rot(int world) { return (SRZ_BAND_ROT % world) ? SRZ_BAND_ROT : (SRZ_BAND_ROT ? 1 : 0); }
+__host__ __device__ inline int band_of(int lb, int rank, int world) {
+  int j = (rank - band_rot(world) * lb) % world;
+  return lb * world + (j < 0 ? j + world : j);
+}
+__host__ __device__ inline int rank_of_band(int b, int world) { return (b + band_rot(world) * (b / world)) % world; }
 constexpr uint32_t NO_TRI = 0xffffffffu;
 // per-frame atomic counters sit 128 bytes apart: atomics on the words of ONE cache line serialise (~10 ns each across the
 // device) as if they were one address — with 16 frames of 4096^2 that was the whole of k_raster's time

@@ -618,15 +618,18 @@ __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t
   for (uint32_t i = (uint32_t)tid; i < nlb; i += 256u) s_cnt[i] = 0u;
   if (tid == 0) s_misc[0] = 0u;
   __syncthreads();
-  // the local bands of triangle k: lb0[k] .. lb0[k] + nb[k] - 1 (band b is local iff b % world == rank; local index b / world)
+  // the local bands of triangle k: lb0[k] .. lb0[k] + nb[k] - 1 (band b is local iff rank_of_band(b) == rank; local index b / world: one
+  // band of every group of `world` bands, so the local indices a box reaches are consecutive)
   int lb0[GROUP_K], nb[GROUP_K];
 #pragma unroll
   for (int k = 0; k < (int)GROUP_K; ++k) {
     lb0[k] = 0, nb[k] = 0;
     if (keep[k]) {
       const int b0 = (int)bb[k].sy >> 5, b1 = (int)bb[k].ey >> 5;
-      const int first = b0 + ((rank - b0) % world + world) % world;
-      if (first <= b1) lb0[k] = first / world, nb[k] = (b1 - first) / world + 1;
+      int g0 = b0 / world, g1 = b1 / world;
+      if (band_of(g0, rank, world) < b0) ++g0;
+      if (band_of(g1, rank, world) > b1) --g1;
+      if (g0 <= g1) lb0[k] = g0, nb[k] = g1 - g0 + 1;
       if (nb[k] > 64) s_misc[0] = 1u, nb[k] = 0; // (benign race: every writer stores 1)
       for (int j = 0; j < nb[k]; ++j) atomicAdd(&s_cnt[lb0[k] + j], 1u);
     }
@@ -669,7 +672,7 @@ __device__ __forceinline__ void bucket_group(const RenderArgs &a, const uint32_t
       for (int j = 0; j < nb[k]; ++j) {
         uint32_t xr_j = xr;
         if (tight) {
-          const int b = (lb0[k] + j) * world + rank;
+          const int b = band_of(lb0[k] + j, rank, world);
           int X0 = bb[k].sx, X1 = bb[k].ex;
           float mn, mx;
           slab_extent(P[k][0], P[k][1], P[k][3], P[k][4], P[k][6], P[k][7], (float)max(b * BAND, (int)bb[k].sy) - m,
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   __syncthreads();
   const uint32_t n_tris = fd->n_tris;
   const bool packed = (fd->flags & FD_PACKED) != 0u; // (tile-list entries carry the batch above the index)
-  const int band = (int)lb * a.shard_world + a.shard_rank;
+  const int band = band_of((int)lb, a.shard_rank, a.shard_world);
   const int y0 = band * BAND, y1 = y0 + BAND - 1;
   const SRZ_CAS u32x2 *bbox = as_const(reinterpret_cast<const u32x2 *>(a.bbox + fd->tri_off));
   const SRZ_CAS uint32_t *chunk_rows = as_const(a.chunk_rows) + fd->chunk_off;
@@ -1542,7 +1545,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
     if (flags & SRZ_FUSED_CLEAR) {
       const int W = fd->width, H = fd->height;
       const uint32_t lb = tile / a.tiles_x;
-      const int tx0 = (int)(tile % a.tiles_x) * TILE, ty0 = ((int)lb * a.shard_world + a.shard_rank) * BAND;
+      const int tx0 = (int)(tile % a.tiles_x) * TILE, ty0 = band_of((int)lb, a.shard_rank, a.shard_world) * BAND;
       const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
       const size_t plane = (size_t)a.local_rows * (size_t)W;
       float *out0 = a.out + (size_t)frame * a.frame_stride + (size_t)lb * BAND * (size_t)W;
@@ -1575,7 +1578,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 5 : 1) void k_raster(Rende
   const uint32_t lb = tile / a.tiles_x;
   const int W = fd->width, H = fd->height;
   const int tx0 = (int)(tile % a.tiles_x) * TILE;
-  const int band = (int)lb * a.shard_world + a.shard_rank;
+  const int band = band_of((int)lb, a.shard_rank, a.shard_world);
   const int ty0 = band * BAND;
   const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
   const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
@@ -1955,7 +1958,7 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
     const uint32_t n_tris = fd->n_tris;
     const uint32_t flags = fd->flags | a.flags_or;
     const int tx0 = (int)(tile % a.tiles_x) * TILE;
-    const int band = (int)lb * a.shard_world + a.shard_rank;
+    const int band = band_of((int)lb, a.shard_rank, a.shard_world);
     const int ty0 = band * BAND;
     const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
     const bool fused = (flags & SRZ_FUSED_CLEAR) != 0;
@@ -2168,7 +2171,7 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
     if (!((fd->flags | a.flags_or) & SRZ_FUSED_CLEAR)) continue;
     const int W = fd->width, H = fd->height;
-    const int band = (int)lb * a.shard_world + a.shard_rank;
+    const int band = band_of((int)lb, a.shard_rank, a.shard_world);
     const int rows = min(BAND, H - band * BAND);
     const size_t plane = (size_t)a.local_rows * (size_t)W;
     float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W;
@@ -2320,7 +2323,7 @@ void k_shade(RenderArgs a) {
     const SRZ_CAS ShadeDescG *sdesc = as_const(ap->sdesc) + batch_off;
     const bool sd_staged = fd->n_batches <= STAGE_SD; // workgroup-uniform
 
-    const int band = (int)lb * ap->shard_world + ap->shard_rank;
+    const int band = band_of((int)lb, ap->shard_rank, ap->shard_world);
     const int tx0 = (int)tx * TILE, ty0 = band * BAND;
     const int tx1 = min(tx0 + TILE, W) - 1, ty1 = min(ty0 + BAND, H) - 1;
     const size_t plane = (size_t)ap->local_rows * (size_t)W;
@@ -2708,7 +2711,7 @@ void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint3
 
 // ================================================================================================================
 // k_deinterleave — the multi-GPU exchange's second half.  The all-gather leaves every rank's shard one after the other,
-//   gathered[rank][frame][plane][local band][32 rows][row bytes]        (band b = local band * world + rank),
+//   gathered[rank][frame][plane][local band][32 rows][row bytes]        (band b = band_of(local band, rank): srz_device.h),
 // and this kernel restores the reference's row-major planes,
 //   full[frame][plane][band][32 rows][row bytes],
 // in one pass of 16-byte (or 4-byte) units: consecutive threads copy consecutive units of one destination row.
@@ -2719,8 +2722,9 @@ __global__ __launch_bounds__(256) void k_deinterleave(const U *gathered, U *full
   const uint64_t band_units = band_units_, total = (uint64_t)n_fp * bands_per_rank * world * band_units;
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t in_band = i % band_units, b = i / band_units; // b = (frame-plane, local band, rank) of the destination
-    const uint32_t rank = (uint32_t)(b % world), lb = (uint32_t)((b / world) % bands_per_rank);
     const uint64_t fp = b / ((uint64_t)world * bands_per_rank);
+    const uint32_t bb = (uint32_t)(b % ((uint64_t)world * bands_per_rank)); // the band inside its frame-plane
+    const uint32_t rank = (uint32_t)rank_of_band((int)bb, (int)world), lb = bb / world;
     full[i] = __builtin_nontemporal_load(gathered + (((uint64_t)rank * n_fp + fp) * bands_per_rank + lb) * band_units + in_band);
   }
 }

@@ -1,4 +1,4 @@
-"""Multi-GPU band sharding: one process per GPU, 32-row bands dealt round-robin, RCCL all-gather to reassemble.
+"""Multi-GPU band sharding: one process per GPU, 32-row bands dealt round-robin with a rotation per round (band_of), RCCL all-gather to reassemble.
 
 Mirrors shard_layout() in csrc/srz_api.hip.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in
 the CPU tests)."""
@@ -7,10 +7,29 @@ from . import abi
 BAND = 32
 
 
+BAND_ROT = 5  # = SRZ_BAND_ROT in csrc/srz_device.h
+
+
+def band_rot(world):
+    return BAND_ROT if BAND_ROT % world else 1
+
+
+def band_of(lb, rank, world):
+    """band of local band `lb` of `rank`: every group of `world` consecutive bands hands one band to every rank, rotated by
+    band_rot(world) steps per group (= band_of in csrc/srz_device.h, where the choice is measured)"""
+    return lb * world + (rank - band_rot(world) * lb) % world
+
+
+def rank_of_band(b, world):
+    return (b + band_rot(world) * (b // world)) % world
+
+
 def shard_layout(height, rank, world):
     """→ dict(n_bands, n_local_bands, bands_per_rank, local_rows) for the ctx of (rank, world)."""
     n_bands = (height + BAND - 1) // BAND
-    n_local = (n_bands - rank + world - 1) // world if rank < n_bands else 0
+    n_local = n_bands // world
+    if band_of(n_local, rank, world) < n_bands:
+        n_local += 1
     per_rank = (n_bands + world - 1) // world
     local_rows = height if world == 1 else per_rank * BAND
     return {"n_bands": n_bands, "n_local_bands": n_local, "bands_per_rank": per_rank, "local_rows": local_rows}
@@ -21,7 +40,7 @@ def band_rows(height, rank, world):
     lay = shard_layout(height, rank, world)
     out = []
     for lb in range(lay["n_local_bands"]):
-        b = lb * world + rank
+        b = band_of(lb, rank, world)
         out.append((lb, b, b * BAND, min(height, (b + 1) * BAND)))
     return out
 
@@ -32,10 +51,14 @@ def deinterleave(gathered, world, out=None):
     w_, n_frames, planes, local_rows, width = gathered.shape
     assert w_ == world and local_rows % BAND == 0
     bpr = local_rows // BAND
-    src = gathered.view(world, n_frames, planes, bpr, BAND, width).permute(1, 2, 3, 0, 4, 5)
+    import torch
+    src = gathered.view(world, n_frames, planes, bpr, BAND, width)
     if out is None:
-        return src.reshape(n_frames, planes, bpr * world * BAND, width)
-    out.view(n_frames, planes, bpr, world, BAND, width).copy_(src)
+        out = torch.empty((n_frames, planes, bpr * world * BAND, width), dtype=gathered.dtype, device=gathered.device)
+    dst = out.view(n_frames, planes, bpr, world, BAND, width)  # [.., group g, position j in the group, ..]: band g * world + j
+    for j in range(world):  # position j of group g belongs to rank (j + rot * g) % world, whose local band g it is
+        ranks = (band_rot(world) * torch.arange(bpr, device=gathered.device) + j) % world
+        dst[:, :, :, j] = src[ranks, :, :, torch.arange(bpr, device=gathered.device)].permute(1, 2, 0, 3, 4)
     return out
 
 
@@ -43,7 +66,7 @@ def gathered_row(gathered, frame, plane, row, world):
     """the row `row` of a frame inside a rank-major gathered buffer [world, frames, planes, bands_per_rank*32, W] (the layout
     srz_frameset_allgather_inplace leaves; = srz_frameset_gathered_row_offset)"""
     band = row // BAND
-    return gathered[band % world, frame, plane, (band // world) * BAND + row % BAND]
+    return gathered[rank_of_band(band, world), frame, plane, (band // world) * BAND + row % BAND]
 
 
 def all_gather_inplace(gathered, rank, group=None):
