@@ -32,6 +32,7 @@ constexpr int LDS_STRIDE = 32;
 #endif
 __host__ __device__ inline int band_rot(int world) { return (SRZ_BAND_ROT % world) ? SRZ_BAND_ROT : (SRZ_BAND_ROT ? 1 : 0); }
 __host__ __device__ inline int band_of(int lb, int rank, int world) {
+  if (world == 1) return lb; // (the single-GPU case pays no division: a wave-uniform branch in the kernels)
   int j = (rank - band_rot(world) * lb) % world;
   return lb * world + (j < 0 ? j + world : j);
 }
