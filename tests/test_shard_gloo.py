@@ -161,3 +161,32 @@ def test_shard_layout_matches_the_c_side_rules():
                 assert lay["local_rows"] == (h if world == 1 else lay["bands_per_rank"] * 32)
                 owned += [b for (_, b, _, _) in rows]
             assert sorted(owned) == list(range((h + 31) // 32))   # every band owned exactly once
+
+
+def test_band_map_is_a_partition_for_every_world_and_height():
+    """the band → rank map (srz/parallel.py = band_of / rank_of_band in csrc/srz_device.h: every round of `world` consecutive bands hands one
+    band to every rank, rotated by five ranks per round — one where five is a multiple of the world): every band has exactly one owner,
+    a rank's local band index is the round's index, counts differ by at most one, and the torch de-interleave agrees with the row rule"""
+    import torch
+    for world in (1, 2, 3, 4, 5, 7, 8, 10):
+        for height in (1, 31, 32, 33, 70, 513, 1000, 1024, 2048, 4096):
+            n_bands = (height + 31) // 32
+            owner = {}
+            counts = []
+            for r in range(world):
+                lay = parallel.shard_layout(height, r, world)
+                rows = parallel.band_rows(height, r, world)
+                assert len(rows) == lay["n_local_bands"] <= lay["bands_per_rank"] == (n_bands + world - 1) // world
+                counts.append(len(rows))
+                for lb, b, r0, r1 in rows:
+                    assert b not in owner and parallel.rank_of_band(b, world) == r and b // world == lb and (r0, r1) == (b * 32, min(height, b * 32 + 32))
+                    owner[b] = r
+            assert sorted(owner) == list(range(n_bands)) and max(counts) - min(counts) <= 1, (world, height)
+    assert parallel.band_rot(8) == 5 and parallel.band_rot(5) == 1 and parallel.band_rot(1) == 1
+    # a rank meets a different slice of a 16-band object in consecutive rounds (what the rotation is for)
+    assert {parallel.band_of(lb, 3, 8) % 16 for lb in range(8)} == {(3 - 5 * lb) % 8 + 8 * (lb % 2) for lb in range(8)}
+    for world, bpr in ((3, 4), (8, 5), (5, 3)):
+        g = torch.arange(world * 2 * 4 * bpr * 32 * 3, dtype=torch.float32).view(world, 2, 4, bpr * 32, 3)
+        full = parallel.deinterleave(g, world)
+        for row in range(0, bpr * world * 32, 5):
+            assert torch.equal(full[1, 2, row], parallel.gathered_row(g, 1, 2, row, world))
