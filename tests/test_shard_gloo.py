@@ -167,7 +167,7 @@ def test_band_map_is_a_partition_for_every_world_and_height():
     """the band → rank map (srz/parallel.py = band_of / rank_of_band in csrc/srz_device.h: every round of `world` consecutive bands hands one
     band to every rank, rotated by five ranks per round — one where five is a multiple of the world): every band has exactly one owner,
     a rank's local band index is the round's index, counts differ by at most one, and the torch de-interleave agrees with the row rule"""
-    import torch
+    from srz import parallel
     for world in (1, 2, 3, 4, 5, 7, 8, 10):
         for height in (1, 31, 32, 33, 70, 513, 1000, 1024, 2048, 4096):
             n_bands = (height + 31) // 32
