@@ -798,7 +798,12 @@ __global__ __launch_bounds__(256) void k_chunks(RenderArgs a) {
 constexpr int BIN_MAX_WAVES = 8; // launched with 2, 4 or 8 waves: the walk is latency-bound, so short streams take small
                                  // workgroups (more of them resident per CU), long ones more waves per band
 constexpr uint32_t BIN_STAGE = 4096; // indices of one band staged in LDS (16 KB)
-// dynamic LDS = (3 * tiles_x + 64 * waves + 4 + BIN_STAGE) dwords: [count | offset | fill cursor] per tile, per-wave marks, stage
+// The entries a wave met on its first walk (count) are kept in LDS for its second one (fill): BIN_KEEP batches of 64 per wave in the
+// eight-wave build (16 KB: the wave slots, not the LDS, bound that build to four workgroups per CU), one batch in the smaller ones (whose
+// eight workgroups per CU leave 2 KB each).  A wave that met more batches, or a DESC_RAW group, walks again as before (round 6)
+__host__ __device__ constexpr uint32_t bin_keep(uint32_t waves) { return waves >= 8u ? 4u : 1u; }
+// dynamic LDS = (3 * tiles_x + 64 * waves + 4 + BIN_STAGE + 128 * waves * bin_keep(waves)) dwords: [count | offset | fill cursor] per tile,
+// per-wave marks, stage, kept entries
 __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   const int BIN_WAVES = (int)(blockDim.x >> 6);
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -806,6 +811,7 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   uint32_t *s_cnt = s_dyn, *s_off = s_dyn + TX, *s_fill = s_dyn + 2 * TX, *s_marks = s_dyn + 3 * TX;
   uint32_t *s_misc = s_marks + 64 * BIN_WAVES; // [0] first index of the band in pool[] (or UNLISTED), [1] indices of the band
   uint32_t *s_stage = s_misc + 4;
+
   // same XCD-aware decomposition as k_raster: workgroup i bins frame (i % 8) of its group of 8 frames, so a frame's
   // records are written through the L2 of the XCD that will rasterise it
   const uint32_t wg = blockIdx.x, xcd = wg & 7u, jj = wg >> 3;
@@ -814,6 +820,11 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   const SRZ_CAS FrameDesc *fd = as_const(a.frames) + frame;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t KEEP = bin_keep((uint32_t)BIN_WAVES);
+  // (8-byte entries: behind the stage, at an even dword whatever the frame's width in tiles)
+  u32x2 *s_keep = reinterpret_cast<u32x2 *>(s_dyn + ((3u * TX + 64u * (uint32_t)BIN_WAVES + 4u + BIN_STAGE + 1u) & ~1u)) + (size_t)wave * KEEP * 64u;
+  uint32_t n_seen = 0;    // batches this wave has met on the current walk (wave-uniform)
+  bool keep_ok = true;    // ... and none of them came from a DESC_RAW group
   for (uint32_t w = threadIdx.x; w < 3 * TX; w += blockDim.x) s_dyn[w] = 0u;
   uint32_t *s_mark = s_marks + 64 * wave;
   s_mark[lane] = 0u;
@@ -895,14 +906,16 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
         const uint32_t e_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)sl * 4, (int)off);
         const uint32_t e = P0 + (uint32_t)lane;
         const bool valid = e < T;
-        u32x2 en = {0u, 0u};
+        u32x2 en = {0u, 1u}; // (tiles 1 .. 0: none)
         if (valid) en = ents[(size_t)(r0 + sl) * ENT_PER_GROUP + e_off + (e - e_excl)];
+        if (n_seen < KEEP) s_keep[n_seen * 64u + (uint32_t)lane] = en;
+        ++n_seen;
         fn(en.x, valid, (int)(en.y & 0xffffu), (int)(en.y >> 16));
       }
       first = b - nbat; // (b is the first batch index >= nbat that is this wave's: b - nbat < NW)
       uint32_t ri = 0;  // DESC_RAW groups of the round: dealt to the waves one by one
       for (unsigned long long mr = __ballot(raw); mr != 0ull; mr &= mr - 1ull, ++ri)
-        if (ri % NW == (uint32_t)wave) walk_raw(r0 + (uint32_t)__builtin_ctzll(mr), fn);
+        if (ri % NW == (uint32_t)wave) keep_ok = false, walk_raw(r0 + (uint32_t)__builtin_ctzll(mr), fn);
     }
   };
   // ---- pass 1: tile counts ---------------------------------------------------------------------------------------------
@@ -945,7 +958,7 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
   uint32_t *out = a.pool + base;
   const uint32_t run = s_misc[1];
   const bool staged = run <= BIN_STAGE; // workgroup-uniform
-  walk([&](uint32_t t, bool hit, int tlo, int thi) {
+  auto fill = [&](uint32_t t, bool hit, int tlo, int thi) {
     if (hit)
       for (int tx = tlo; tx <= thi; ++tx) {
         const uint32_t slot = s_off[tx] + atomicAdd(&s_fill[tx], 1u);
@@ -954,7 +967,16 @@ __global__ __launch_bounds__(64 * BIN_MAX_WAVES) void k_bin(RenderArgs a) {
         else
           out[slot] = t;
       }
-  });
+  };
+  if (keep_ok && n_seen <= KEEP) { // (wave-uniform) everything this wave met on the first walk is still in LDS: no second walk
+    for (uint32_t k = 0; k < n_seen; ++k) {
+      const u32x2 en = s_keep[k * 64u + (uint32_t)lane];
+      fill(en.x, true, (int)(en.y & 0xffffu), (int)(en.y >> 16)); // (a lane without an entry kept tiles 1 .. 0)
+    }
+  } else {
+    n_seen = KEEP; // (nothing more is kept)
+    walk(fill);
+  }
   if (staged) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < run; i += blockDim.x) out[i] = s_stage[i];
@@ -2926,7 +2948,7 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
   static const int env = getenv("SRZ_BIN_WAVES") ? atoi(getenv("SRZ_BIN_WAVES")) : 0;
   // (measured: 4 waves best at 5.9 k triangles, 8 at 94 k; a job with fewer band workgroups than CUs is pure latency: 8)
   const int waves = env ? env : ((max_tris <= 32768u && (uint32_t)n_frames * a.n_local_bands > 256u) ? 4 : BIN_MAX_WAVES);
-  const size_t lds = sizeof(uint32_t) * (3u * (size_t)a.tiles_x + 64u * waves + 4u + BIN_STAGE);
+  const size_t lds = sizeof(uint32_t) * (3u * (size_t)a.tiles_x + 64u * waves + 4u + BIN_STAGE + 2u + 128u * waves * bin_keep((uint32_t)waves));
   hipLaunchKernelGGL(k_bin, dim3(groups * 8u * a.n_local_bands), dim3(64 * waves), lds, s, a);
 }
 
