@@ -60,6 +60,8 @@ struct srz_ctx {
   int env_sub_batch = 0;
   bool env_no_packed = false; // SRZ_NO_PACKED (tests): see srz_frameset::no_packed
   bool env_no_turns = false;  // SRZ_NO_TURNS (A/B): renders on different streams do not wait for each other's k_raster
+  uint32_t env_clear_wgs = 0; // SRZ_CLEAR_WGS: fixed grid of the side-stream clear (else measured per set, srz_frameset::ClearTune)
+  bool env_no_clear_tune = false, env_clear_trace = false; // SRZ_CLEAR_TUNE=0: the grid stays at 96; SRZ_CLEAR_TRACE=1: the measurement goes to stderr
   bool opt_approx_shade = false; // SRZ_OPT_APPROX_SHADE (srz_set_option): framesets created from now on shade in the tolerance mode
   bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
   hipStream_t stream2 = nullptr; // k_clear runs here, next to k_raster
@@ -146,6 +148,26 @@ struct srz_frameset {
   uint32_t tiles_x = 0, max_tiles = 0;
   bool have_stats = false;
   bool update_failed = false; // an update re-classified the frames but could not get the work lists they need: renders are refused
+  // Grid of the side-stream clear (launch_clear).  Its best size depends on what the clear runs beside — about 96 workgroups on configs 2
+  // and 3, 256 on config 4, 160 on config 5, with 4 .. 8 % of a step between the best and the worst of them — so a set MEASURES it.
+  // Renders CLEAR_TUNE_SKIP .. +18 of a set run the candidates in blocks of three renders, in the order a b c c b a (the first renders
+  // after idle run up to 10 % slower, bench.py `priming`: the mirrored order takes a linear ramp out of the comparison).  A sample is the
+  // time from the end of the set's previous render to the end of this one — with two lanes that is one render of each lane, what the
+  // throughput is made of; the first sample of a block (the previous candidate's tail) is dropped, and the candidate with the smallest
+  // median of its four samples wins.  The pixels are the same bits under every grid.  SRZ_CLEAR_WGS fixes the grid, SRZ_CLEAR_TUNE=0
+  // leaves it at 96, SRZ_CLEAR_TRACE=1 prints the measurement.
+  static constexpr int CLEAR_TUNE_CANDS = 3, CLEAR_TUNE_BLOCK = 3, CLEAR_TUNE_SKIP = 6, CLEAR_TUNE_RENDERS = 2 * CLEAR_TUNE_CANDS * CLEAR_TUNE_BLOCK;
+  static constexpr uint32_t clear_tune_cand[CLEAR_TUNE_CANDS] = {96, 160, 256};
+  static constexpr int clear_tune_cand_of(int j) { // candidate of the measurement's render j
+    return j / CLEAR_TUNE_BLOCK < CLEAR_TUNE_CANDS ? j / CLEAR_TUNE_BLOCK : 2 * CLEAR_TUNE_CANDS - 1 - j / CLEAR_TUNE_BLOCK;
+  }
+  struct ClearTune {
+    uint32_t wgs = 96; // the grid in use outside the measurement
+    bool done = false;
+    int renders = 0;   // renders of the set enqueued so far (counted until the measurement is complete)
+    hipEvent_t ev[CLEAR_TUNE_RENDERS] = {}; // ev[j]: end of the measurement's render j
+    float med[CLEAR_TUNE_CANDS];
+  } clear_tune;
   srz_stats stats{};
 };
 
@@ -494,6 +516,43 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     chunk = ((n_all + parts - 1) / parts + 7) / 8 * 8;
   }
   const size_t tpf = (size_t)fs->n_local_bands * fs->tiles_x;
+  // the side clear's grid: measured per set (srz_frameset::ClearTune)
+  uint32_t clear_wgs = ctx->env_clear_wgs ? ctx->env_clear_wgs : fs->clear_tune.wgs;
+  hipEvent_t tune_end = nullptr;
+  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !fs->clear_tune.done && !stats && !detailed && f_count < 0) {
+    using FS = srz_frameset;
+    FS::ClearTune &ct = fs->clear_tune;
+    const int j = ct.renders - FS::CLEAR_TUNE_SKIP;
+    if (j < FS::CLEAR_TUNE_RENDERS) {
+      ++ct.renders;
+      if (j >= 0) {
+        clear_wgs = FS::clear_tune_cand[FS::clear_tune_cand_of(j)];
+        if (!ct.ev[j]) HIP_TRY(ctx, hipEventCreate(&ct.ev[j]));
+        tune_end = ct.ev[j];
+      }
+    } else if (hipEventQuery(ct.ev[FS::CLEAR_TUNE_RENDERS - 1]) == hipSuccess) { // (the last sample has finished, so have the others)
+      float t[FS::CLEAR_TUNE_CANDS][4];
+      int n[FS::CLEAR_TUNE_CANDS] = {};
+      for (int k = 0; k < FS::CLEAR_TUNE_RENDERS; ++k) {
+        if (k % FS::CLEAR_TUNE_BLOCK == 0) continue;
+        const int c = FS::clear_tune_cand_of(k);
+        HIP_TRY(ctx, hipEventElapsedTime(&t[c][n[c]++], ct.ev[k - 1], ct.ev[k]));
+      }
+      int arg = 0;
+      for (int c = 0; c < FS::CLEAR_TUNE_CANDS; ++c) {
+        std::sort(t[c], t[c] + 4);
+        ct.med[c] = 0.5f * (t[c][1] + t[c][2]);
+        if (ct.med[c] < ct.med[arg]) arg = c;
+      }
+      ct.wgs = clear_wgs = FS::clear_tune_cand[arg], ct.done = true;
+      for (hipEvent_t &e : ct.ev) (void)hipEventDestroy(e), e = nullptr;
+      if (ctx->env_clear_trace) {
+        fprintf(stderr, "srz: clear grid of set %p:", (void *)fs);
+        for (int c = 0; c < FS::CLEAR_TUNE_CANDS; ++c) fprintf(stderr, " %u:%.3f", FS::clear_tune_cand[c], ct.med[c]);
+        fprintf(stderr, " ms -> %u\n", ct.wgs);
+      }
+    } else (void)hipGetLastError(); // (hipErrorNotReady is not an error of ours)
+  }
   int part = 0;
   for (int f0 = 0; f0 < n_all; f0 += chunk, ++part) {
     RenderArgs v = a;
@@ -555,7 +614,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[ev], s));
       hipStream_t side_s = ctx->stream2;
       HIP_TRY(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork[ev], 0));
-      launch_clear(v, tiles, true, side_s);
+      launch_clear(v, tiles, true, side_s, clear_wgs);
       // (in front of the join: whatever follows on the launch stream — the next sub-batch's or render's k_setup zeroes the
       // allocators — is ordered behind this copy; it is 16 words behind a kernel that outlasts k_raster)
       if (int rc = copy_demand(side_s)) return rc;
@@ -573,6 +632,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       if (int rc = copy_demand(s)) return rc;
   }
   if (!stats) fs->pool_sized = true;
+  if (tune_end) HIP_TRY(ctx, hipEventRecord(tune_end, s));
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -636,6 +696,9 @@ int srz_create(srz_ctx **out, int device_id) {
   ctx->env_sub_batch = getenv("SRZ_SUB_BATCH") ? atoi(getenv("SRZ_SUB_BATCH")) : 0;
   ctx->env_no_packed = getenv("SRZ_NO_PACKED") != nullptr;
   ctx->env_no_turns = getenv("SRZ_NO_TURNS") != nullptr;
+  ctx->env_clear_wgs = getenv("SRZ_CLEAR_WGS") ? (uint32_t)std::max(atoi(getenv("SRZ_CLEAR_WGS")), 0) : 0u;
+  ctx->env_no_clear_tune = getenv("SRZ_CLEAR_TUNE") && atoi(getenv("SRZ_CLEAR_TUNE")) == 0;
+  ctx->env_clear_trace = getenv("SRZ_CLEAR_TRACE") && atoi(getenv("SRZ_CLEAR_TRACE")) != 0;
   ctx->opt_pool_lazy = getenv("SRZ_POOL_LAZY") != nullptr;
   for (int i = 0; i < MAX_TEX; ++i) ctx->h_tex[i] = TexDesc{nullptr, 0, 0}, ctx->d_texmem[i] = nullptr;
   auto bail = [&](const char *what, hipError_t err) {
@@ -1162,6 +1225,8 @@ void srz_frameset_destroy(srz_ctx *ctx, srz_frameset *fs) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
   }
+  for (hipEvent_t &e : fs->clear_tune.ev)
+    if (e) (void)hipEventDestroy(e), e = nullptr;
   free_frameset_buffers(fs);
   delete fs;
 }
@@ -1313,8 +1378,8 @@ int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4) {
 /* diagnostic (tests): what the LAST render of the set left in its counters — out4 = { tiles the ordered rasteriser (k_raster_slow)
  * took, tiles the FAST shading builds handed to the generic one, the tile-list pool's capacity per sub-pool, the largest demand a
  * sub-pool has reported }.  Waits for the device. */
-int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out4) {
-  if (!ctx || !fs || !out4) return ctx ? fail(ctx, SRZ_E_INVALID, "srz_frameset_debug_counters: null argument") : SRZ_E_INVALID;
+int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out6) {
+  if (!ctx || !fs || !out6) return ctx ? fail(ctx, SRZ_E_INVALID, "srz_frameset_debug_counters: null argument") : SRZ_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   uint32_t h[2] = {0, 0};
@@ -1324,7 +1389,8 @@ int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out4) 
     const uint32_t v = static_cast<volatile uint32_t *>(fs->h_pool_heads)[((i / fs->pool_n_sub) * 64u + i % fs->pool_n_sub) * CNT_STRIDE];
     if (v > need) need = v;
   }
-  out4[0] = h[0], out4[1] = h[1], out4[2] = fs->pool_sub_cap, out4[3] = need;
+  out6[0] = h[0], out6[1] = h[1], out6[2] = fs->pool_sub_cap, out6[3] = need;
+  out6[4] = ctx->env_clear_wgs ? ctx->env_clear_wgs : fs->clear_tune.wgs, out6[5] = fs->clear_tune.done ? 1u : 0u;
   return SRZ_OK;
 }
 

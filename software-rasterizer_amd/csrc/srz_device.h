@@ -194,7 +194,7 @@ void launch_setup(const RenderArgs &a, int n_frames, uint32_t max_tris, bool sta
 void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_t s);
 void launch_raster(const RenderArgs &a, int n_frames, bool stats, hipStream_t s);
 bool raster_four_waves(const RenderArgs &a); // the latency build of k_raster serves this job (it also reports the pool's demand)
-void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s);
+void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s, uint32_t wgs);
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, bool approx, hipStream_t s);
 void launch_resolve8(const float *planes, uint8_t *out, uint32_t n_frames, uint32_t rows, uint32_t W, uint64_t frame_stride,
                      hipStream_t s);

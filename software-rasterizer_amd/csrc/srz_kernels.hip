@@ -2184,11 +2184,17 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
 // One work item = one band of one frame, written ROW-MAJOR: a wave-instruction covers 1 KiB of one framebuffer row
 // (256 consecutive pixels), so runs of untouched tiles become long contiguous DRAM bursts instead of 128-byte tile rows
 // 4 KiB apart — the same bytes occupy the memory system for less time, which is what the kernels beside it pay for.
+// One work item = ONE PLANE of one band of one frame (round 6; rounds 2-5: one band, its four planes interleaved row by row).  A thread writes
+// its 16 bytes of 32 consecutive rows of the plane: a workgroup streams one plane's rows instead of keeping four streams 4 MB apart going, and
+// the memory system — which is what the compute kernels beside the clear wait for — takes the same bytes in less time: measured beside
+// k_raster / k_shade, two lanes, at each form's best grid: config 2 0.645 -> 0.738 of the roofline, config 3 0.600 -> 0.675, config 4
+// 0.411 -> 0.438, config 5 0.43 -> 0.444 (NOTEBOOK r6 §6; the rows of a plane written one after the other by the whole workgroup — fewer
+// stores in flight per thread — is slower again: 0.67 on config 2).
 __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
-  const uint32_t n_rows = a.n_frames * a.n_local_bands;
+  const uint32_t n_items = a.n_frames * a.n_local_bands * 4u;
   const float inf = __builtin_inff();
-  const float4 inf4 = make_float4(inf, inf, inf, inf), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (uint32_t br = blockIdx.x; br < n_rows; br += gridDim.x) { // br = frame * n_local_bands + lb
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) { // it = (frame * n_local_bands + lb) * 4 + plane
+    const uint32_t br = it >> 2, pl = it & 3u;
     const uint32_t f = br / a.n_local_bands, lb = br % a.n_local_bands;
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
     if (!((fd->flags | a.flags_or) & SRZ_FUSED_CLEAR)) continue;
@@ -2196,25 +2202,22 @@ __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
     const int band = band_of((int)lb, a.shard_rank, a.shard_world);
     const int rows = min(BAND, H - band * BAND);
     const size_t plane = (size_t)a.local_rows * (size_t)W;
-    float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W;
+    float *base = a.out + (size_t)f * a.frame_stride + (size_t)lb * BAND * (size_t)W + pl * plane;
+    const float v = pl == 0u ? inf : 0.f; // (plane 0 = z)
+    const float4 v4 = make_float4(v, v, v, v);
     const SRZ_CAS u32x2 *cnt = as_const(reinterpret_cast<const u32x2 *>(a.tile_info)) + (size_t)br * a.tiles_x;
     for (int x4 = (int)threadIdx.x * 4; x4 < W; x4 += (int)blockDim.x * 4) {
       if (cnt[(uint32_t)x4 / TILE].x != 0u) continue; // some bbox reaches this tile: the rasteriser's
       if (((W & 3) == 0)) {
-        for (int ly = 0; ly < rows; ++ly) {
-          float *g = base + (size_t)ly * W + x4;
-          store_nt(g, inf4), store_nt(g + plane, zero4), store_nt(g + 2 * plane, zero4), store_nt(g + 3 * plane, zero4);
-        }
+        for (int ly = 0; ly < rows; ++ly) store_nt(base + (size_t)ly * W + x4, v4);
       } else { // odd widths: scalar stores, the quad may end at the frame's edge or straddle nothing else (TILE % 4 == 0)
         for (int ly = 0; ly < rows; ++ly)
-          for (int k = 0; k < 4 && x4 + k < W; ++k) {
-            float *g = base + (size_t)ly * W + x4 + k;
-            g[0] = inf, g[plane] = 0.f, g[2 * plane] = 0.f, g[3 * plane] = 0.f;
-          }
+          for (int k = 0; k < 4 && x4 + k < W; ++k) base[(size_t)ly * W + x4 + k] = v;
       }
     }
   }
 }
+
 
 // k_shade is latency-sensitive: measurably slower at 3 waves per SIMD than at 4 — hold the allocator to 128 VGPRs
 #ifndef SRZ_FAST_MINW
@@ -2952,20 +2955,20 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
   hipLaunchKernelGGL(k_bin, dim3(groups * 8u * a.n_local_bands), dim3(64 * waves), lds, s, a);
 }
 
-void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s) {
+void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s, uint32_t wgs) {
   if (max_tiles == 0) return;
-  // Beside k_raster/k_shade the clear is THROTTLED by its grid size, so that the stores spread over the whole pipeline
-  // instead of starving the rasteriser's loads and the shader's register file (measured on MI355X, 256 frames of 1024^2:
-  // 32 WGs → the clear outlives k_shade, 160 → k_raster +50 %; flat optimum around 64).
-  static const uint32_t env = getenv("SRZ_CLEAR_WGS") ? (uint32_t)atoi(getenv("SRZ_CLEAR_WGS")) : 0u;
-  const uint32_t n_rows = a.n_frames * a.n_local_bands;
-  const uint32_t cap = !beside_raster ? 2048u : (env ? env : 64u);
+  // Beside k_raster/k_shade the clear is THROTTLED by its grid size, so that the stores spread over the whole pipeline instead of starving
+  // the rasteriser's loads and the shader's register file.  The best grid depends on what runs beside it (config 2: 96 workgroups, 0.738
+  // of the roofline against 0.727 at 80 and 0.681 at 128; config 4: 0.406 at 96, 0.438 at 256), so the caller measures it per set
+  // (srz_api.hip, srz_frameset::ClearTune).  Work items are planes of bands.
+  const uint32_t n_items = a.n_frames * a.n_local_bands * 4u;
+  const uint32_t cap = !beside_raster ? 2048u : (wgs ? wgs : 96u);
   (void)max_tiles;
   static const uint32_t env_thr = getenv("SRZ_CLEAR_THREADS") ? (uint32_t)atoi(getenv("SRZ_CLEAR_THREADS")) : 0u; // (A/B: 64 / 128 / 256)
   const uint32_t thr = (beside_raster && env_thr) ? env_thr : 256u;
   // (round 6, same box: the clear's stores as nt / sc1 nt / sc0 sc1 nt / sc1 / plain give config 4 3.10 / 3.22 / 3.26 / 3.29 / 3.29 ms per
   // step and config 5 5.25 / 5.48 / 5.44 / 5.71 / 5.62: nt, as round 3 found on config 2)
-  hipLaunchKernelGGL(k_clear, dim3(n_rows < cap ? n_rows : cap), dim3(thr), 0, s, a);
+  hipLaunchKernelGGL(k_clear, dim3(n_items < cap ? n_items : cap), dim3(thr), 0, s, a);
 }
 
 void launch_shade(const RenderArgs &a, uint32_t max_tiles, bool stats, uint32_t fast_mask, bool any_generic, bool approx, hipStream_t s) {

@@ -140,10 +140,10 @@ class FrameSet:
                                                     _stream(stream)))
 
     def debug_counters(self):
-        """(tests) what the last render left: {slow_tiles, redo_tiles, pool_sub_cap, pool_demand}; waits for the device"""
-        out = (C.c_uint32 * 4)()
+        """(tests) what the last render left: {slow_tiles, redo_tiles, pool_sub_cap, pool_demand, clear_wgs, clear_tuned}; waits for the device"""
+        out = (C.c_uint32 * 6)()
         self.ctx._check(lib().srz_frameset_debug_counters(self.ctx.h, self.h, out))
-        return dict(zip(("slow_tiles", "redo_tiles", "pool_sub_cap", "pool_demand"), (int(x) for x in out)))
+        return dict(zip(("slow_tiles", "redo_tiles", "pool_sub_cap", "pool_demand", "clear_wgs", "clear_tuned"), (int(x) for x in out)))
 
     def exchange_bytes(self, what=abi.EXCHANGE_PLANES):
         return int(lib().srz_frameset_exchange_bytes(self.ctx.h, self.h, what))

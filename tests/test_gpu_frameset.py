@@ -424,6 +424,39 @@ def test_two_lanes_at_batch_size_take_turns_and_match_the_oracle(orc):
     ctx.close()
 
 
+def test_clear_grid_is_measured_and_every_grid_gives_the_same_bits(orc):
+    """a batch-sized set (8 frames of 1024^2: the clear runs on the side stream) measures the grid of its clear over its first 24
+    renders (srz_api.hip, srz_frameset::ClearTune): every one of them — each candidate grid, frames of one plane per work item — leaves
+    the oracle's bits, untouched tiles included (the buffer is poisoned before every render), and after the measurement the set
+    reports a grid out of the candidates"""
+    import srz
+    ctx = srz.Context(0)
+    ctx.texture_upload(scenes.TEX_SPOT, scenes.spot_texture())
+    frames = [scenes.config2(i) for i in range(8)]
+    fs = ctx.frameset(frames)
+    assert fs.debug_counters()["clear_tuned"] == 0
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    first = None
+    for k in range(26):
+        out.fill_(float("nan"))
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
+        torch.cuda.synchronize()
+        if first is None:
+            first = out.clone()
+            got = first.cpu().numpy()
+            for i in (0, 7):
+                ref = orc.draw(frames[i])[1]
+                for p in range(4):
+                    assert np.array_equal(bits(got[i, p]), bits(ref[p])), (i, p)
+        else:
+            assert torch.equal(out.view(torch.int32), first.view(torch.int32)), k
+    dc = fs.debug_counters()
+    assert dc["clear_tuned"] == 1 and dc["clear_wgs"] in (96, 160, 256), dc
+    fs.close()
+    ctx.close()
+
+
 def test_lane_renderer_default_flags_are_the_fused_clear(orc):
     """LaneRenderer.render(ptr) with no flags must mean what FrameSet.render(ptr, bytes) means: the buffer counts as just
     cleared.  (Round 2's default was SRZ_UNIFIED = accumulate with 8-wide semantics: a torch.empty buffer then fed garbage
