@@ -55,7 +55,8 @@ APPROX_CASES = [("spot_texture_1024", 256, 10), ("spot_bunny_phong_1080p", 128, 
                 ("spot_x8_overdraw_4096", 64, 10)]
 PER_CONFIG = ("spot_bunny_phong_1080p", "spot_x16_texture_2048", "spot_x8_overdraw_4096", "readme_spot_crate_1024", "spot_texture_1024_p7.5")
 HBM_BYTES = 288e9  # per MI355X
-PRIME_TO = 20      # untimed renders in front of every timed region, the --warmup steps included (time_single_gpu)
+PRIME_TO = 26      # untimed renders in front of every timed region, the --warmup steps included (time_single_gpu): the clock ramp
+                   # after idle, and the 24 renders over which a frameset measures the grid of its clear (srz_api.hip, ClearTune)
 
 
 def kernel_source_hash():
@@ -326,8 +327,8 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2, unprimed=False):
         lanes = 2 if case.n_frames >= 64 else 1
     lr = case.lanes(lanes)
     # priming (not counted as warm-up; reported as `priming_steps`): the first ~13 renders after idle run up to 10 % slower
-    # (clock ramp, first touch of the list pool: tools/step_series_probe.py prints the series) — a short --warmup ends inside
-    # that ramp.  The headline case therefore times TWO regions: first exactly what the arguments say from idle (W untimed steps,
+    # (clock ramp, first touch of the list pool: tools/step_series_probe.py prints the series), and renders 6..23 of a frameset are the
+    # ones that try the candidate grids of its clear (srz_api.hip, srz_frameset::ClearTune) — a short --warmup ends inside both.  The headline case therefore times TWO regions: first exactly what the arguments say from idle (W untimed steps,
     # K timed: `value_unprimed` / `ms_per_step_unprimed`), then W more untimed steps and K timed ones in the steady state (`value`);
     # the other workloads make sure of PRIME_TO untimed renders in all and time one region.
     unprimed_dt = None
@@ -362,6 +363,10 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2, unprimed=False):
     n_l = len(lr.sets)
     per_step = [max(samples[i:i + n_l]) for i in range(0, len(samples) - n_l + 1, n_l)]  # a step ends with its slowest lane
     kt["lane_launch_ms"], kt["total_ms"], kt["lanes"] = kt["total_ms"], span_ms / max(steps, 1), n_l
+    # grid of each lane's side-stream clear as its frameset measured it during the priming renders (srz_api.hip, ClearTune) and whether
+    # the measurement was complete before the timed region
+    dc = [s_.debug_counters() for s_ in lr.sets]
+    kt["clear_wgs"], kt["clear_tuned"] = [d_["clear_wgs"] for d_ in dc], all(d_["clear_tuned"] for d_ in dc)
     # ---- not part of the measurement: the same batch in ONE piece on ONE stream (whole-launch time, then the kernel split)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -574,6 +579,7 @@ def case_record(case, steps, dt, kt, per_step, frag_total, vis_total):
                      "traffic_over_algorithmic": pm["hbm_bytes_per_step"] / case.algo_bytes if pm else None,
                      "algorithmic_bytes_per_launch": case.algo_bytes, "launch_ms": kt["total_ms"],
                      "lanes": kt.get("lanes", 1), "lane_launch_ms": kt.get("lane_launch_ms"),
+                     "clear_wgs": kt.get("clear_wgs"), "clear_tuned": kt.get("clear_tuned"),
                      "one_stream": {"ms_per_step": kt.get("one_stream_ms_per_step"), "launch_ms": kt.get("split_total_ms"),
                                     "k_setup_bin_ms": kt["bin_ms"], "k_raster_ms": kt["raster_ms"], "k_shade_ms": kt["shade_ms"]}},
     }
@@ -589,7 +595,7 @@ def per_config_summary(rec):
                 "frames": rec["frames"], "reference_published_draw_ms_median": 17.06}
     r, v = rec["roofline"], rec.get("valu") or {}
     return {"scope": rec["scope"], "frames_per_step": rec["frames_per_step"], "lanes": rec["lanes"], "frames_per_sec": rec["frames_per_sec"],
-            "ms_per_step": rec["ms_per_step"], "frac": r["frac"], "traffic_over_algorithmic": r["traffic_over_algorithmic"],
+            "ms_per_step": rec["ms_per_step"], "frac": r["frac"], "traffic_over_algorithmic": r["traffic_over_algorithmic"], "clear_wgs": r.get("clear_wgs"),
             "valu_pipe_frac_est": v.get("valu_pipe_frac_est"),
             "one_stream_us": {"setup_bin": r["one_stream"]["k_setup_bin_ms"] * 1e3, "raster": r["one_stream"]["k_raster_ms"] * 1e3,
                               "shade": r["one_stream"]["k_shade_ms"] * 1e3}}
@@ -683,7 +689,7 @@ def emit(res, extras):
     roof = res["roofline"]
     one = roof.get("one_stream") or {}
     r = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "traffic_over_algorithmic",
-                                  "algorithmic_bytes_per_launch", "launch_ms", "lanes", "launches_timed", "kernel_source_hash")}
+                                  "algorithmic_bytes_per_launch", "launch_ms", "lanes", "clear_wgs", "launches_timed", "kernel_source_hash")}
     r["kernel"] = "k_setup+k_bin+k_raster+k_shade in line, k_clear beside them (second stream); HIP events on the launch streams"
     # both peaks, as BASELINE.md §4 asks: 8.0 TB/s spec (`peak`, `frac`) and the 6.29 TB/s measured float4 copy of the guide
     r["peak_measured"] = HBM_MEASURED_COPY_GBS
@@ -701,12 +707,13 @@ def emit(res, extras):
                        "ref_published_draw_ms": v["reference_published_draw_ms_median"]}
         else:
             pc[key] = {"F": v["frames_per_step"], "fps": v["frames_per_sec"], "ms": v["ms_per_step"], "frac": v["frac"],
-                       "t_over_a": v["traffic_over_algorithmic"], "us": [v["one_stream_us"][k] for k in ("setup_bin", "raster", "shade")]}
+                       "t_over_a": v["traffic_over_algorithmic"], "us": [v["one_stream_us"][k] for k in ("setup_bin", "raster", "shade")],
+                       "wgs": v.get("clear_wgs")}
             if not tag:  # flat scalars: the driver's parser keeps a nested object's scalars only
                 r["frac_" + key], r["fps_" + key] = v["frac"], v["frames_per_sec"]
                 r["frac_measured_" + key] = v["frac"] * HBM_PEAK_GBS / HBM_MEASURED_COPY_GBS
     r["per_config"] = pc
-    r["per_config_keys"] = "F frames/step, fps, ms/step (2 lanes), frac of 8 TB/s (frac_measured*: of the 6.29 TB/s measured copy), traffic/algorithmic, us = one-stream [setup+bin, raster, shade]"
+    r["per_config_keys"] = "F frames/step, fps, ms/step (2 lanes), frac of 8 TB/s (frac_measured*: of the 6.29 TB/s measured copy), traffic/algorithmic, us = one-stream [setup+bin, raster, shade], wgs = measured grid of each lane's clear"
     mg = roof.get("multi_gpu_emulated")
     if mg is not None:
         r["multi_gpu_emulated"] = mg if "error" in mg else {

@@ -155,8 +155,9 @@ struct srz_frameset {
   // time from the end of the set's previous render to the end of this one — with two lanes that is one render of each lane, what the
   // throughput is made of; the first sample of a block (the previous candidate's tail) is dropped, and the candidate with the smallest
   // median of its four samples wins.  The pixels are the same bits under every grid.  SRZ_CLEAR_WGS fixes the grid, SRZ_CLEAR_TUNE=0
-  // leaves it at 96, SRZ_CLEAR_TRACE=1 prints the measurement.
+  // leaves it at 96, SRZ_CLEAR_TRACE=1 prints the measurement.  Every CLEAR_TUNE_AGAIN renders the set measures again.
   static constexpr int CLEAR_TUNE_CANDS = 3, CLEAR_TUNE_BLOCK = 3, CLEAR_TUNE_SKIP = 6, CLEAR_TUNE_RENDERS = 2 * CLEAR_TUNE_CANDS * CLEAR_TUNE_BLOCK;
+  static constexpr int CLEAR_TUNE_AGAIN = 4096; // renders after which the measurement is repeated (the scene of a sceneset changes under it)
   static constexpr uint32_t clear_tune_cand[CLEAR_TUNE_CANDS] = {96, 160, 256};
   static constexpr int clear_tune_cand_of(int j) { // candidate of the measurement's render j
     return j / CLEAR_TUNE_BLOCK < CLEAR_TUNE_CANDS ? j / CLEAR_TUNE_BLOCK : 2 * CLEAR_TUNE_CANDS - 1 - j / CLEAR_TUNE_BLOCK;
@@ -165,6 +166,7 @@ struct srz_frameset {
     uint32_t wgs = 96; // the grid in use outside the measurement
     bool done = false;
     int renders = 0;   // renders of the set enqueued so far (counted until the measurement is complete)
+    int since = 0;     // renders since the last measurement
     hipEvent_t ev[CLEAR_TUNE_RENDERS] = {}; // ev[j]: end of the measurement's render j
     float med[CLEAR_TUNE_CANDS];
   } clear_tune;
@@ -519,13 +521,17 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   // the side clear's grid: measured per set (srz_frameset::ClearTune)
   uint32_t clear_wgs = ctx->env_clear_wgs ? ctx->env_clear_wgs : fs->clear_tune.wgs;
   hipEvent_t tune_end = nullptr;
-  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !fs->clear_tune.done && !stats && !detailed && f_count < 0) {
+  if (side && fs->clear_tune.done && !stats && !detailed && f_count < 0 && ++fs->clear_tune.since >= srz_frameset::CLEAR_TUNE_AGAIN) {
+    // what the clear runs beside may have changed (srz_sceneset_update): measure again, from the grid in use (18 of 4096 renders)
+    fs->clear_tune.done = false, fs->clear_tune.since = 0, fs->clear_tune.renders = srz_frameset::CLEAR_TUNE_SKIP;
+  }
+  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !fs->clear_tune.done && !stats && f_count < 0) {
     using FS = srz_frameset;
     FS::ClearTune &ct = fs->clear_tune;
     const int j = ct.renders - FS::CLEAR_TUNE_SKIP;
     if (j < FS::CLEAR_TUNE_RENDERS) {
-      ++ct.renders;
-      if (j >= 0) {
+      if (detailed) { // (the per-kernel timing mode puts barriers into the stream: not a sample, and not counted)
+      } else if (++ct.renders, j >= 0) {
         clear_wgs = FS::clear_tune_cand[FS::clear_tune_cand_of(j)];
         if (!ct.ev[j]) HIP_TRY(ctx, hipEventCreate(&ct.ev[j]));
         tune_end = ct.ev[j];

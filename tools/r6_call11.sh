@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 6, call 11: the clear's work items frame-minor (concurrent workgroups in different frames) against the shipped order
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r6; mkdir -p $O; rm -f $O/call11.log
+B=$PWD/software-rasterizer_amd/build
+run() { # workload frames wgs
+  for l in cur clrfm cur clrfm; do
+    SRZ_LIB_PATH=$B/$l.so bash tools/r6_env_sweep.sh $O/call11.log "$1:$2" "SRZ_CLEAR_WGS=$3 L=$l" || exit 1
+  done
+}
+run spot_bunny_phong_1080p 128 96
+run spot_x8_overdraw_4096 64 160
+cat $O/call11.log
