@@ -525,7 +525,12 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     // what the clear runs beside may have changed (srz_sceneset_update): measure again, from the grid in use (18 of 4096 renders)
     fs->clear_tune.done = false, fs->clear_tune.since = 0, fs->clear_tune.renders = srz_frameset::CLEAR_TUNE_SKIP;
   }
-  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !fs->clear_tune.done && !stats && f_count < 0) {
+  auto capturing = [&]() { // (a caller capturing its stream into a hipGraph: no event queries, no timing events — the grid in use stays)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) return (void)hipGetLastError(), true;
+    return cs != hipStreamCaptureStatusNone;
+  };
+  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !fs->clear_tune.done && !stats && f_count < 0 && !capturing()) {
     using FS = srz_frameset;
     FS::ClearTune &ct = fs->clear_tune;
     const int j = ct.renders - FS::CLEAR_TUNE_SKIP;
@@ -539,20 +544,23 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     } else if (hipEventQuery(ct.ev[FS::CLEAR_TUNE_RENDERS - 1]) == hipSuccess) { // (the last sample has finished, so have the others)
       float t[FS::CLEAR_TUNE_CANDS][4];
       int n[FS::CLEAR_TUNE_CANDS] = {};
-      for (int k = 0; k < FS::CLEAR_TUNE_RENDERS; ++k) {
+      bool ok = true; // (a render of the measurement that failed half-way left an event unrecorded: then the grid in use stays)
+      for (int k = 0; k < FS::CLEAR_TUNE_RENDERS && ok; ++k) {
         if (k % FS::CLEAR_TUNE_BLOCK == 0) continue;
         const int c = FS::clear_tune_cand_of(k);
-        HIP_TRY(ctx, hipEventElapsedTime(&t[c][n[c]++], ct.ev[k - 1], ct.ev[k]));
+        ok = hipEventElapsedTime(&t[c][n[c]++], ct.ev[k - 1], ct.ev[k]) == hipSuccess;
       }
+      if (!ok) (void)hipGetLastError();
       int arg = 0;
-      for (int c = 0; c < FS::CLEAR_TUNE_CANDS; ++c) {
+      for (int c = 0; c < FS::CLEAR_TUNE_CANDS && ok; ++c) {
         std::sort(t[c], t[c] + 4);
         ct.med[c] = 0.5f * (t[c][1] + t[c][2]);
         if (ct.med[c] < ct.med[arg]) arg = c;
       }
-      ct.wgs = clear_wgs = FS::clear_tune_cand[arg], ct.done = true;
+      if (ok) ct.wgs = FS::clear_tune_cand[arg];
+      clear_wgs = ct.wgs, ct.done = true;
       for (hipEvent_t &e : ct.ev) (void)hipEventDestroy(e), e = nullptr;
-      if (ctx->env_clear_trace) {
+      if (ctx->env_clear_trace && ok) {
         fprintf(stderr, "srz: clear grid of set %p:", (void *)fs);
         for (int c = 0; c < FS::CLEAR_TUNE_CANDS; ++c) fprintf(stderr, " %u:%.3f", FS::clear_tune_cand[c], ct.med[c]);
         fprintf(stderr, " ms -> %u\n", ct.wgs);
