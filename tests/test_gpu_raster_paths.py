@@ -327,7 +327,8 @@ def test_tight_rectangles_stay_conservative_on_adversarial_shapes(ctx, orc, seed
 
 def test_tight_rectangles_in_the_throughput_build(ctx, orc):
     """the same shapes as a BATCH: 18 frames of 20 x 13 tiles = 4680 tiles — above the 4096 of the four-waves-per-tile build, so
-    this is k_raster<1>, k_clear on its side stream and the frameset path; every frame against the oracle"""
+    this is k_raster<1> (which clears the tiles no bbox reaches itself: the side-stream clear starts at 8192 tiles) and the frameset
+    path; every frame against the oracle"""
     w, h = 640, 416
     lights = [((100.0, 100.0, -50.0), (300.0, 300.0, 300.0)), ((400.0, 50.0, 80.0), (200.0, 200.0, 200.0))]
     shaders = [abi.SHADER_NORMAL, abi.SHADER_PHONG, abi.SHADER_TEXTURE]
@@ -343,6 +344,38 @@ def test_tight_rectangles_in_the_throughput_build(ctx, orc):
         rc, ref, _ = orc.draw(f)
         assert rc == 0
         same(got[i], ref, f"batch frame {i}")
+
+
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 3)])
+def test_side_stream_clear_odd_width_ragged_height(orc, rank, world):
+    """k_clear on its side stream (sets of >= 8192 tiles) on frames whose width is no multiple of 4 (scalar stores, the last quad cut
+    by the frame's edge) and whose height is no multiple of 32 (a ragged last band), most tiles untouched, the buffer poisoned with
+    NaN before every render — unsharded and as rank 1 of 3 (bands dealt by band_of; the shard's rows against the oracle's); rendered
+    often enough that every candidate grid of the clear has been in use"""
+    import srz
+    from srz import parallel
+    w, h = 333, 301   # 11 x 10 tiles
+    n_frames = 84 if world == 1 else 252
+    uniq = [frame(adversarial_tris(4000 + i, 25, w, h), w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR) for i in range(12)]
+    refs = [np.stack(orc.draw(f)[1]) for f in uniq]
+    c = srz.Context(0, rank, world)
+    fs = c.frameset([uniq[i % 12] for i in range(n_frames)])
+    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    rows = parallel.band_rows(h, rank, world)
+    s = torch.cuda.current_stream().cuda_stream
+    for it in range(26):
+        out.fill_(float("nan"))
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
+        torch.cuda.synchronize()
+        if it in (0, 7, 10, 13, 25):   # (first render, one render of each candidate's first block, the measured grid)
+            got = out.cpu().numpy()
+            for i in (0, 5, 11, n_frames - 1):
+                ref = refs[i % 12]
+                for (lb, b, r0, r1) in rows:
+                    a_ = got[i][:, lb * 32: lb * 32 + (r1 - r0)].view(np.uint32)
+                    assert np.array_equal(a_, ref[:, r0:r1].view(np.uint32)), (it, i, b)
+    assert fs.debug_counters()["clear_tuned"] == 1
+    fs.close(), c.close()
 
 
 def test_owner_ids_by_triangle_index(orc, monkeypatch):
