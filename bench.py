@@ -328,7 +328,8 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2, unprimed=False):
     lr = case.lanes(lanes)
     # priming (not counted as warm-up; reported as `priming_steps`): the first ~13 renders after idle run up to 10 % slower
     # (clock ramp, first touch of the list pool: tools/step_series_probe.py prints the series), and renders 6..23 of a frameset are the
-    # ones that try the candidate grids of its clear (srz_api.hip, srz_frameset::ClearTune) — a short --warmup ends inside both.  The headline case therefore times TWO regions: first exactly what the arguments say from idle (W untimed steps,
+    # ones that try the candidate grids of its clear (srz_api.hip, srz_frameset::ClearTune) — a short --warmup ends inside both.
+    # The headline case therefore times TWO regions: first exactly what the arguments say from idle (W untimed steps,
     # K timed: `value_unprimed` / `ms_per_step_unprimed`), then W more untimed steps and K timed ones in the steady state (`value`);
     # the other workloads make sure of PRIME_TO untimed renders in all and time one region.
     unprimed_dt = None

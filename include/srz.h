@@ -345,7 +345,7 @@ int srz_verify_fastpow(srz_ctx *ctx, float p, uint64_t *out4);
 int srz_verify_fastlen(srz_ctx *ctx, uint64_t *out5);
 /* diagnostic only (tests): counters the LAST render of the set left — out6 = { tiles taken by the ordered rasteriser, tiles the FAST
  * shading builds handed to the generic build, capacity of a tile-list sub-pool, largest demand a sub-pool reported, workgroups of the
- * side-stream clear (a set measures them over its first 24 renders and again every 4096), 1 once that measurement has been taken }; waits for the device */
+ * side-stream clear (a batch-sized set measures them on the device within its first 24 renders, and again every 4096), 1 once that measurement has been taken }; waits for the device */
 int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out6);
 /* diagnostic only: raw device counters of the last stats run (layout = csrc/srz_device.h ST_*); returns their count */
 int srz_debug_counters(srz_ctx *ctx, uint64_t *out, int n);

@@ -149,26 +149,20 @@ struct srz_frameset {
   bool have_stats = false;
   bool update_failed = false; // an update re-classified the frames but could not get the work lists they need: renders are refused
   // Grid of the side-stream clear (launch_clear).  Its best size depends on what the clear runs beside — about 96 workgroups on configs 2
-  // and 3, 256 on config 4, 160 on config 5, with 4 .. 8 % of a step between the best and the worst of them — so a set MEASURES it.
-  // Renders CLEAR_TUNE_SKIP .. +18 of a set run the candidates in blocks of three renders, in the order a b c c b a (the first renders
-  // after idle run up to 10 % slower, bench.py `priming`: the mirrored order takes a linear ramp out of the comparison).  A sample is the
-  // time from the end of the set's previous render to the end of this one — with two lanes that is one render of each lane, what the
-  // throughput is made of; the first sample of a block (the previous candidate's tail) is dropped, and the candidate with the smallest
-  // median of its four samples wins.  The pixels are the same bits under every grid.  SRZ_CLEAR_WGS fixes the grid, SRZ_CLEAR_TUNE=0
-  // leaves it at 96, SRZ_CLEAR_TRACE=1 prints the measurement.  Every CLEAR_TUNE_AGAIN renders the set measures again.
-  static constexpr int CLEAR_TUNE_CANDS = 3, CLEAR_TUNE_BLOCK = 3, CLEAR_TUNE_SKIP = 6, CLEAR_TUNE_RENDERS = 2 * CLEAR_TUNE_CANDS * CLEAR_TUNE_BLOCK;
-  static constexpr int CLEAR_TUNE_AGAIN = 4096; // renders after which the measurement is repeated (the scene of a sceneset changes under it)
-  static constexpr uint32_t clear_tune_cand[CLEAR_TUNE_CANDS] = {96, 160, 256};
-  static constexpr int clear_tune_cand_of(int j) { // candidate of the measurement's render j
-    return j / CLEAR_TUNE_BLOCK < CLEAR_TUNE_CANDS ? j / CLEAR_TUNE_BLOCK : 2 * CLEAR_TUNE_CANDS - 1 - j / CLEAR_TUNE_BLOCK;
-  }
+  // and 3, 256 on config 4, 160 on config 5, with 4 .. 8 % of a step between the best and the worst of them — so a set MEASURES it, on
+  // the device (srz_device.h, ClearCtl / k_clear_tune): from render CLEAR_TUNE_SKIP on the clear is launched with CLEAR_GRID_MAX workgroups
+  // of which the device-side state says how many take part, and a one-thread kernel ends each of the next <= 18 renders; the decision
+  // arrives in a word of mapped host memory, and from the render that finds it there the host launches exactly that grid.  The pixels are
+  // the same bits under every grid.  SRZ_CLEAR_WGS fixes the grid, SRZ_CLEAR_TUNE=0 leaves it at 96, SRZ_CLEAR_TRACE=1 prints the
+  // measurement.  Every CLEAR_TUNE_AGAIN renders the set measures again (the scene of a sceneset changes under it).
+  static constexpr int CLEAR_TUNE_SKIP = 6, CLEAR_TUNE_AGAIN = 4096;
   struct ClearTune {
-    uint32_t wgs = 96; // the grid in use outside the measurement
-    bool done = false;
-    int renders = 0;   // renders of the set enqueued so far (counted until the measurement is complete)
-    int since = 0;     // renders since the last measurement
-    hipEvent_t ev[CLEAR_TUNE_RENDERS] = {}; // ev[j]: end of the measurement's render j
-    float med[CLEAR_TUNE_CANDS];
+    uint32_t wgs = CLEAR_GRID_DEFAULT; // the grid in use outside the measurement
+    bool done = false;  // the host has seen the decision of the current measurement
+    int renders = 0;    // renders of the set enqueued so far (counted until the measurement's last render)
+    int since = 0;      // renders since the last decision
+    ClearCtl *d_ctl = nullptr;  // device-side state
+    uint32_t *h_wgs = nullptr;  // mapped host memory: 0 until k_clear_tune has decided
   } clear_tune;
   srz_stats stats{};
 };
@@ -299,6 +293,8 @@ void free_frameset_buffers(srz_frameset *fs) {
   (void)hipFree(fs->d_pool);
   (void)hipFree(fs->d_pool_heads);
   if (fs->h_pool_heads) (void)hipHostFree(fs->h_pool_heads);
+  if (fs->clear_tune.h_wgs) (void)hipHostFree(fs->clear_tune.h_wgs), fs->clear_tune.h_wgs = nullptr;
+  if (fs->clear_tune.d_ctl) (void)hipFree(fs->clear_tune.d_ctl), fs->clear_tune.d_ctl = nullptr;
   (void)hipFree(fs->d_tile_info);
   (void)hipFree(fs->d_slow_list);
   (void)hipFree(fs->d_slow_count);
@@ -518,54 +514,38 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
     chunk = ((n_all + parts - 1) / parts + 7) / 8 * 8;
   }
   const size_t tpf = (size_t)fs->n_local_bands * fs->tiles_x;
-  // the side clear's grid: measured per set (srz_frameset::ClearTune)
+  // the side clear's grid: measured per set, on the device (srz_frameset::ClearTune)
   uint32_t clear_wgs = ctx->env_clear_wgs ? ctx->env_clear_wgs : fs->clear_tune.wgs;
-  hipEvent_t tune_end = nullptr;
-  if (side && fs->clear_tune.done && !stats && !detailed && f_count < 0 && ++fs->clear_tune.since >= srz_frameset::CLEAR_TUNE_AGAIN) {
-    // what the clear runs beside may have changed (srz_sceneset_update): measure again, from the grid in use (18 of 4096 renders)
-    fs->clear_tune.done = false, fs->clear_tune.since = 0, fs->clear_tune.renders = srz_frameset::CLEAR_TUNE_SKIP;
-  }
-  auto capturing = [&]() { // (a caller capturing its stream into a hipGraph: no event queries, no timing events — the grid in use stays)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess) return (void)hipGetLastError(), true;
-    return cs != hipStreamCaptureStatusNone;
-  };
-  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !fs->clear_tune.done && !stats && f_count < 0 && !capturing()) {
-    using FS = srz_frameset;
-    FS::ClearTune &ct = fs->clear_tune;
-    const int j = ct.renders - FS::CLEAR_TUNE_SKIP;
-    if (j < FS::CLEAR_TUNE_RENDERS) {
-      if (detailed) { // (the per-kernel timing mode puts barriers into the stream: not a sample, and not counted)
-      } else if (++ct.renders, j >= 0) {
-        clear_wgs = FS::clear_tune_cand[FS::clear_tune_cand_of(j)];
-        if (!ct.ev[j]) HIP_TRY(ctx, hipEventCreate(&ct.ev[j]));
-        tune_end = ct.ev[j];
+  bool tune_stamp = false;
+  if (side && !ctx->env_clear_wgs && !ctx->env_no_clear_tune && !stats && f_count < 0 && fs->clear_tune.d_ctl) {
+    srz_frameset::ClearTune &ct = fs->clear_tune;
+    if (ct.done && !detailed && ++ct.since >= srz_frameset::CLEAR_TUNE_AGAIN) {
+      // what the clear runs beside may have changed (srz_sceneset_update): measure again (<= 18 of 4096 renders)
+      ct.done = false, ct.since = 0, ct.renders = srz_frameset::CLEAR_TUNE_SKIP;
+      *static_cast<volatile uint32_t *>(ct.h_wgs) = 0u; // (no k_clear_tune is in flight: the host stopped launching them when it saw the decision)
+      HIP_TRY(ctx, hipMemsetAsync(ct.d_ctl, 0, sizeof(ClearCtl), s));
+    }
+    if (!ct.done) {
+      const uint32_t h = *static_cast<volatile uint32_t *>(ct.h_wgs);
+      const int j = ct.renders - srz_frameset::CLEAR_TUNE_SKIP;
+      if (h != 0u) { // decided: launch that grid from now on
+        ct.wgs = clear_wgs = h, ct.done = true;
+        if (ctx->env_clear_trace) {
+          ClearCtl c;
+          if (hipMemcpy(&c, ct.d_ctl, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "srz: clear grid of set %p:", (void *)fs);
+            for (int i = 0; i < CLEAR_CANDS; ++i) fprintf(stderr, " %u:%.3f", CLEAR_CAND[i], c.score[i] * 1e-5f);
+            fprintf(stderr, " ms (0: dropped after the first pass) -> %u\n", h);
+          }
+        }
+      } else if (j < 0) {
+        if (!detailed) ++ct.renders;
+      } else { // measuring (or the decision has not reached the host yet): the device says how many of the grid take part
+        clear_wgs = CLEAR_GRID_MAX, a.clear_wgs_dev = &ct.d_ctl->wgs;
+        // (the per-kernel timing mode puts barriers into the stream: not a sample, and not counted)
+        if (j < CLEAR_TUNE_RENDERS && !detailed) ++ct.renders, tune_stamp = true;
       }
-    } else if (hipEventQuery(ct.ev[FS::CLEAR_TUNE_RENDERS - 1]) == hipSuccess) { // (the last sample has finished, so have the others)
-      float t[FS::CLEAR_TUNE_CANDS][4];
-      int n[FS::CLEAR_TUNE_CANDS] = {};
-      bool ok = true; // (a render of the measurement that failed half-way left an event unrecorded: then the grid in use stays)
-      for (int k = 0; k < FS::CLEAR_TUNE_RENDERS && ok; ++k) {
-        if (k % FS::CLEAR_TUNE_BLOCK == 0) continue;
-        const int c = FS::clear_tune_cand_of(k);
-        ok = hipEventElapsedTime(&t[c][n[c]++], ct.ev[k - 1], ct.ev[k]) == hipSuccess;
-      }
-      if (!ok) (void)hipGetLastError();
-      int arg = 0;
-      for (int c = 0; c < FS::CLEAR_TUNE_CANDS && ok; ++c) {
-        std::sort(t[c], t[c] + 4);
-        ct.med[c] = 0.5f * (t[c][1] + t[c][2]);
-        if (ct.med[c] < ct.med[arg]) arg = c;
-      }
-      if (ok) ct.wgs = FS::clear_tune_cand[arg];
-      clear_wgs = ct.wgs, ct.done = true;
-      for (hipEvent_t &e : ct.ev) (void)hipEventDestroy(e), e = nullptr;
-      if (ctx->env_clear_trace && ok) {
-        fprintf(stderr, "srz: clear grid of set %p:", (void *)fs);
-        for (int c = 0; c < FS::CLEAR_TUNE_CANDS; ++c) fprintf(stderr, " %u:%.3f", FS::clear_tune_cand[c], ct.med[c]);
-        fprintf(stderr, " ms -> %u\n", ct.wgs);
-      }
-    } else (void)hipGetLastError(); // (hipErrorNotReady is not an error of ours)
+    }
   }
   int part = 0;
   for (int f0 = 0; f0 < n_all; f0 += chunk, ++part) {
@@ -646,7 +626,7 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       if (int rc = copy_demand(s)) return rc;
   }
   if (!stats) fs->pool_sized = true;
-  if (tune_end) HIP_TRY(ctx, hipEventRecord(tune_end, s));
+  if (tune_stamp) launch_clear_tune(fs->clear_tune.d_ctl, fs->clear_tune.h_wgs, s);
   if (timed) {
     HIP_TRY(ctx, hipEventRecord(ep.t3, s));
     ctx->ev_used.push_back(ep);
@@ -927,6 +907,11 @@ static int build_frameset(srz_ctx *ctx, const srz_frame *frames, int n_frames, s
     // k_raster's first workgroup (no copy, no event, no query on the launch path), batches copy it on the clear's side stream
     FS_TRY(hipHostMalloc((void **)&fs->h_pool_heads, sizeof(uint32_t) * CNT_STRIDE * 64 * srz_frameset::DEMAND_PARTS, hipHostMallocMapped | hipHostMallocCoherent));
     if (e == hipSuccess) std::memset(fs->h_pool_heads, 0, sizeof(uint32_t) * CNT_STRIDE * 64 * srz_frameset::DEMAND_PARTS);
+    // the measurement of the side clear's grid (srz_frameset::ClearTune): device-side state, and the word its decision arrives in
+    FS_TRY(dev_alloc((void **)&fs->clear_tune.d_ctl, sizeof(ClearCtl)));
+    if (e == hipSuccess) FS_TRY(hipMemset(fs->clear_tune.d_ctl, 0, sizeof(ClearCtl)));
+    FS_TRY(hipHostMalloc((void **)&fs->clear_tune.h_wgs, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (e == hipSuccess) *fs->clear_tune.h_wgs = 0u;
     FS_TRY(dev_alloc((void **)&fs->d_tile_info, sizeof(uint2) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_list, sizeof(uint32_t) * fs->max_tiles));
     FS_TRY(dev_alloc((void **)&fs->d_slow_count, 2 * sizeof(uint32_t)));
@@ -1239,8 +1224,6 @@ void srz_frameset_destroy(srz_ctx *ctx, srz_frameset *fs) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
   }
-  for (hipEvent_t &e : fs->clear_tune.ev)
-    if (e) (void)hipEventDestroy(e), e = nullptr;
   free_frameset_buffers(fs);
   delete fs;
 }
@@ -1404,7 +1387,8 @@ int srz_frameset_debug_counters(srz_ctx *ctx, srz_frameset *fs, uint32_t *out6) 
     if (v > need) need = v;
   }
   out6[0] = h[0], out6[1] = h[1], out6[2] = fs->pool_sub_cap, out6[3] = need;
-  out6[4] = ctx->env_clear_wgs ? ctx->env_clear_wgs : fs->clear_tune.wgs, out6[5] = fs->clear_tune.done ? 1u : 0u;
+  const uint32_t decided = fs->clear_tune.h_wgs ? *static_cast<volatile uint32_t *>(fs->clear_tune.h_wgs) : 0u;
+  out6[4] = ctx->env_clear_wgs ? ctx->env_clear_wgs : (decided ? decided : fs->clear_tune.wgs), out6[5] = (fs->clear_tune.done || decided) ? 1u : 0u;
   return SRZ_OK;
 }
 

@@ -185,7 +185,28 @@ struct RenderArgs {
   uint32_t flags_or;      // OR-ed into every frame's flags (SRZ_FUSED_CLEAR / SRZ_UNIFIED)
   unsigned long long *stats;
   unsigned long long *timeline; // diagnostic (STATS variant only): per tile {start, end (wall clock 100 MHz), hw_id, blocks}
+  const uint32_t *clear_wgs_dev; // k_clear: workgroups that take part, read on the device (ClearCtl::wgs; 0 = the first candidate); null: the whole grid
 };
+
+// The grid of the side-stream clear is MEASURED per frameset, on the device (srz_api.hip, srz_frameset::ClearTune; k_clear_tune): while a
+// set measures, k_clear is launched with CLEAR_GRID_MAX workgroups of which the first ClearCtl::wgs take part, and a one-thread kernel at
+// the end of every render reads the wall clock, files the time since the previous render's end under the grid in use and moves on —
+// candidates a b c in blocks of CLEAR_TUNE_BLOCK renders (the first sample of a block, the previous grid's tail, is dropped); those
+// within 5 % of the best go round once more in the mirrored order c b a (the first renders after idle run up to 10 % slower: the mirror
+// takes a linear ramp out of the comparison), the smallest median of the four samples wins.  No host synchronisation, no event query: the
+// decision takes effect with the next render whatever the host's run-ahead, and reaches the host through a word of mapped memory.
+constexpr int CLEAR_CANDS = 3, CLEAR_TUNE_BLOCK = 3, CLEAR_TUNE_RENDERS = 2 * CLEAR_CANDS * CLEAR_TUNE_BLOCK;
+constexpr uint32_t CLEAR_CAND[CLEAR_CANDS] = {96, 160, 256};
+constexpr uint32_t CLEAR_GRID_MAX = 256, CLEAR_GRID_DEFAULT = 96;
+struct ClearCtl {
+  uint32_t wgs;                  // workgroups of the NEXT render's clear (0: CLEAR_CAND[0] — the state after a memset)
+  uint32_t cur, pos, phase, done, alive;
+  uint32_t n[CLEAR_CANDS];
+  unsigned long long last;       // wall clock (100 MHz) at the end of the previous render
+  float t[CLEAR_CANDS][4];       // samples, wall-clock ticks
+  float score[CLEAR_CANDS];      // what the decision compared (ticks; 0: dropped after the first pass)
+};
+void launch_clear_tune(ClearCtl *ctl, uint32_t *h_wgs, hipStream_t s);
 
 void launch_vertex(const DrawDesc *draws, uint32_t n_draws, uint32_t max_faces, srz_tri *tris, float *tri_pos, const FrameDesc *frames,
                    BBox *bbox_out, hipStream_t s);

@@ -2193,7 +2193,14 @@ __global__ __launch_bounds__(64) void k_raster_slow(RenderArgs a) {
 __global__ __launch_bounds__(256) void k_clear(RenderArgs a) {
   const uint32_t n_items = a.n_frames * a.n_local_bands * 4u;
   const float inf = __builtin_inff();
-  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) { // it = (frame * n_local_bands + lb) * 4 + plane
+  // the workgroups that take part: the whole grid, or — while the set measures its grid (srz_device.h, ClearCtl) — the first `wgs` of it
+  uint32_t n_wgs = gridDim.x;
+  if (a.clear_wgs_dev) {
+    const uint32_t w = *as_const(a.clear_wgs_dev);
+    n_wgs = min(w ? w : CLEAR_CAND[0], gridDim.x);
+    if (blockIdx.x >= n_wgs) return;
+  }
+  for (uint32_t it = blockIdx.x; it < n_items; it += n_wgs) { // it = (frame * n_local_bands + lb) * 4 + plane
     const uint32_t br = it >> 2, pl = it & 3u;
     const uint32_t f = br / a.n_local_bands, lb = br % a.n_local_bands;
     const SRZ_CAS FrameDesc *fd = as_const(a.frames) + f;
@@ -2955,12 +2962,58 @@ void launch_bin(const RenderArgs &a, int n_frames, uint32_t max_tris, hipStream_
   hipLaunchKernelGGL(k_bin, dim3(groups * 8u * a.n_local_bands), dim3(64 * waves), lds, s, a);
 }
 
+// End of a measurement render (one thread; srz_device.h, ClearCtl): file the sample, move to the next grid or decide.
+__global__ void k_clear_tune(ClearCtl *c, uint32_t *h_wgs) {
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+  if (c->done) return;
+  if (c->pos > 0 && c->n[c->cur] < 4u) c->t[c->cur][c->n[c->cur]++] = (float)(now - c->last);
+  c->last = now;
+  if (++c->pos < (uint32_t)CLEAR_TUNE_BLOCK) return;
+  c->pos = 0; // a block has ended
+  int next = -1;
+  if (c->phase == 0u) {
+    if (c->cur + 1u < (uint32_t)CLEAR_CANDS) next = (int)c->cur + 1;
+    else { // the first pass is over: who stays?
+      float m[CLEAR_CANDS], best = 3.0e38f;
+      for (int i = 0; i < CLEAR_CANDS; ++i) m[i] = 0.5f * (c->t[i][0] + c->t[i][1]), best = fminf(best, m[i]);
+      uint32_t alive = 0;
+      for (int i = 0; i < CLEAR_CANDS; ++i)
+        if (m[i] <= 1.05f * best) alive |= 1u << i;
+      c->alive = alive, c->phase = 1u;
+      for (int i = 0; i < CLEAR_CANDS; ++i) c->score[i] = (alive >> i & 1u) ? m[i] : 0.f;
+      if (__popc(alive) > 1) next = 31 - __clz((int)alive); // (the mirrored pass starts with the grid in use)
+    }
+  } else {
+    const uint32_t lower = c->alive & ((1u << c->cur) - 1u);
+    if (lower) next = 31 - __clz((int)lower);
+    else // the mirrored pass is over: medians of four
+      for (int i = 0; i < CLEAR_CANDS; ++i)
+        if (c->alive >> i & 1u) {
+          float *t = c->t[i];
+          for (int x = 1; x < 4; ++x)
+            for (int y = x; y > 0 && t[y] < t[y - 1]; --y) { const float u = t[y]; t[y] = t[y - 1], t[y - 1] = u; }
+          c->score[i] = 0.5f * (t[1] + t[2]);
+        }
+  }
+  if (next >= 0) {
+    c->cur = (uint32_t)next, c->wgs = CLEAR_CAND[next];
+    return;
+  }
+  int arg = -1;
+  for (int i = 0; i < CLEAR_CANDS; ++i)
+    if ((c->alive >> i & 1u) && (arg < 0 || c->score[i] < c->score[arg])) arg = i;
+  c->wgs = CLEAR_CAND[arg < 0 ? 0 : arg], c->done = 1u;
+  __hip_atomic_store(h_wgs, c->wgs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // (mapped host memory: the host launches that grid from now on)
+}
+
+void launch_clear_tune(ClearCtl *ctl, uint32_t *h_wgs, hipStream_t s) { hipLaunchKernelGGL(k_clear_tune, dim3(1), dim3(1), 0, s, ctl, h_wgs); }
+
 void launch_clear(const RenderArgs &a, uint32_t max_tiles, bool beside_raster, hipStream_t s, uint32_t wgs) {
   if (max_tiles == 0) return;
   // Beside k_raster/k_shade the clear is THROTTLED by its grid size, so that the stores spread over the whole pipeline instead of starving
   // the rasteriser's loads and the shader's register file.  The best grid depends on what runs beside it (config 2: 96 workgroups, 0.738
-  // of the roofline against 0.727 at 80 and 0.681 at 128; config 4: 0.406 at 96, 0.438 at 256), so the caller measures it per set
-  // (srz_api.hip, srz_frameset::ClearTune).  Work items are planes of bands.
+  // of the roofline against 0.727 at 80 and 0.681 at 128; config 4: 0.406 at 96, 0.438 at 256), so it is measured per set (srz_device.h,
+  // ClearCtl: while that goes on the grid is CLEAR_GRID_MAX and a.clear_wgs_dev says how many of it work).  Work items are planes of bands.
   const uint32_t n_items = a.n_frames * a.n_local_bands * 4u;
   const uint32_t cap = !beside_raster ? 2048u : (wgs ? wgs : 96u);
   (void)max_tiles;

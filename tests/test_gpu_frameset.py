@@ -425,8 +425,8 @@ def test_two_lanes_at_batch_size_take_turns_and_match_the_oracle(orc):
 
 
 def test_clear_grid_is_measured_and_every_grid_gives_the_same_bits(orc):
-    """a batch-sized set (8 frames of 1024^2: the clear runs on the side stream) measures the grid of its clear over its first 24
-    renders (srz_api.hip, srz_frameset::ClearTune): every one of them — each candidate grid, frames of one plane per work item — leaves
+    """a batch-sized set (8 frames of 1024^2: the clear runs on the side stream) measures the grid of its clear within its first 24
+    renders, on the device (srz_device.h, ClearCtl; srz_api.hip, srz_frameset::ClearTune): every one of them — each candidate grid, frames of one plane per work item — leaves
     the oracle's bits, untouched tiles included (the buffer is poisoned before every render), and after the measurement the set
     reports a grid out of the candidates"""
     import srz

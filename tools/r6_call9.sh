@@ -14,4 +14,4 @@ print('$w', '[${e##*/}]', 'lanes', r.get('lanes'), 'fps', round(d['value']), 'ms
 done
 grep "clear grid" $O/call9.err >> $O/call9.log
 cat $O/call9.log
-python3 -m pytest tests/test_gpu_frameset.py tests/test_gpu_raster_paths.py tests/test_gpu_exchange.py -m gpu -x -q 2>&1 | tail -5
+python3 -m pytest tests/test_gpu_frameset.py tests/test_gpu_raster_paths.py tests/test_gpu_exchange.py tests/test_gpu_bench_line.py -m gpu -x -q 2>&1 | tail -5
