@@ -28,6 +28,8 @@ KERNELS = ("k_setup", "k_chunks", "k_vertex", "k_bin", "k_raster_slow", "k_raste
 def kernel_of(name):
     if "<true" in name:  # counting variants (run once, outside the timed region)
         return None
+    if "k_clear_tune" in name:  # (the one-thread kernel that ends a render while a set measures its clear's grid: not a step's work)
+        return None
     if "k_shade" in name:
         return "k_shade_generic" if "k_shade<false, 0," in name else "k_shade_fast"  # (FAST builds: <false, lights 1..4, bumpy>)
     for k in KERNELS:

@@ -2974,11 +2974,18 @@ __global__ void k_clear_tune(ClearCtl *c, uint32_t *h_wgs) {
   if (c->phase == 0u) {
     if (c->cur + 1u < (uint32_t)CLEAR_CANDS) next = (int)c->cur + 1;
     else { // the first pass is over: who stays?
-      float m[CLEAR_CANDS], best = 3.0e38f;
-      for (int i = 0; i < CLEAR_CANDS; ++i) m[i] = 0.5f * (c->t[i][0] + c->t[i][1]), best = fminf(best, m[i]);
+      // Dropped: a grid that was tried AFTER the best one and is still more than 5 % behind it.  (The first renders after idle, or into
+      // buffers touched for the first time, run slower: the first pass favours the later grids, so an earlier one that looks worse
+      // stays in, and the mirrored pass settles it.)
+      float m[CLEAR_CANDS];
+      int ib = 0;
+      for (int i = 0; i < CLEAR_CANDS; ++i) {
+        m[i] = 0.5f * (c->t[i][0] + c->t[i][1]);
+        if (m[i] < m[ib]) ib = i;
+      }
       uint32_t alive = 0;
       for (int i = 0; i < CLEAR_CANDS; ++i)
-        if (m[i] <= 1.05f * best) alive |= 1u << i;
+        if (i <= ib || m[i] <= 1.05f * m[ib]) alive |= 1u << i;
       c->alive = alive, c->phase = 1u;
       for (int i = 0; i < CLEAR_CANDS; ++i) c->score[i] = (alive >> i & 1u) ? m[i] : 0.f;
       if (__popc(alive) > 1) next = 31 - __clz((int)alive); // (the mirrored pass starts with the grid in use)
