@@ -371,7 +371,7 @@ def time_single_gpu(case, steps, warmup, fence, lanes=2, unprimed=False):
     # ---- not part of the measurement: the same batch in ONE piece on ONE stream (whole-launch time, then the kernel split)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        for _ in range(3):
+        for _ in range(PRIME_TO):  # (this frameset measures the grid of its clear too)
             fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, stream.cuda_stream)
         fence()
         n1 = min(steps, 20)

@@ -540,11 +540,10 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
         }
       } else if (j < 0) {
         if (!detailed) ++ct.renders;
-      } else { // measuring (or the decision has not reached the host yet): the device says how many of the grid take part
+      } else if (!detailed) { // measuring (or the decision has not reached the host yet): the device says how many of the grid take part
         clear_wgs = CLEAR_GRID_MAX, a.clear_wgs_dev = &ct.d_ctl->wgs;
-        // (the per-kernel timing mode puts barriers into the stream: not a sample, and not counted)
-        if (j < CLEAR_TUNE_RENDERS && !detailed) ++ct.renders, tune_stamp = true;
-      }
+        if (j < CLEAR_TUNE_RENDERS) ++ct.renders, tune_stamp = true;
+      } // (the per-kernel timing mode puts barriers into the stream: not a sample, not counted, and rendered with the grid in use before)
     }
   }
   int part = 0;
