@@ -497,19 +497,20 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   if (!side && any_fused) a.clear_in_raster = 1u; // (small job: the rasteriser's own waves clear the tiles no bbox reaches)
   // A LARGE set is rendered as sub-batches of whole frames one after the other on the same stream: what k_raster leaves for
   // k_shade (depth, owner ids) and k_bin for k_raster (records) stays in the 256 MiB Infinity Cache only while the frames in
-  // flight are few — config 2 at 128 / 256 / 384 / 512 frames per launch set: 0.539 / 0.545 / 0.499 / 0.490 of the roofline.
+  // flight are few — config 2 at 128 / 256 / 384 / 512 frames per launch set: 0.539 / 0.545 / 0.499 / 0.490 of the roofline (round 3; round 6,
+  // beside the per-plane clear, 1024 frames on one stream in pieces of 176 / 208 / 256 / 344 / 512: 0.633 / 0.644 / 0.656 / 0.653 / 0.632).
   // A sub-batch is a view: every per-frame array from its first frame on; counters, record pool and work lists are shared
   // (k_setup resets them, and stream order keeps one sub-batch's kernels behind the previous one's).  Counting runs and the
   // per-kernel timing mode render in one piece.
   const int n_all = f_count < 0 ? fs->n_frames : f_count;
   int chunk = n_all;
-  // The sub-batch size is 192 frames' worth of 1024^2 (≈ 197 k tiles: the measured sweet spot), in frames of THIS set — a
-  // rank of an 8-GPU job holds an eighth of every frame and takes 1536 of them at a time; frames so large that fewer than 64
+  // The sub-batch size is 256 frames' worth of 1024^2 (≈ 262 k tiles: the measured sweet spot; 192 until round 6), in frames of THIS
+  // set — a rank of an 8-GPU job holds an eighth of every frame and takes 2048 of them at a time; frames so large that fewer than 64
   // make a sub-batch are left alone (nothing of theirs fits the cache either way).
   const int sub_env = ctx->env_sub_batch; // (tuning / tests: frames per sub-batch)
   const size_t tiles_per_frame = std::max<size_t>((size_t)fs->n_local_bands * fs->tiles_x, 1);
-  const int sub = sub_env > 0 ? sub_env : (int)std::min<size_t>((192u * 1024u / tiles_per_frame + 7u) / 8u * 8u, 1u << 20);
-  if (sub >= 64 && n_all >= sub + sub / 2 + 32 && !stats && !detailed) {
+  const int sub = sub_env > 0 ? sub_env : (int)std::min<size_t>((256u * 1024u / tiles_per_frame + 7u) / 8u * 8u, 1u << 20);
+  if (sub >= 64 && n_all >= sub + sub / 4 && !stats && !detailed) {
     const int parts = (n_all + sub - 1) / sub;
     chunk = ((n_all + parts - 1) / parts + 7) / 8 * 8;
   }

@@ -490,7 +490,7 @@ def test_lane_renderer_default_flags_are_the_fused_clear(orc):
 
 def test_large_set_rendered_as_sub_batches_matches_the_oracle(orc, monkeypatch):
     """a large set is rendered as sub-batches of whole frames one after the other (shared counters, pool and work lists; the
-    size is 192 frames' worth of 1024^2 in tiles — forced to 104 frames here, small frames being cheap to check): 328 frames,
+    size is 256 frames' worth of 1024^2 in tiles — forced to 104 frames here, small frames being cheap to check): 328 frames,
     twice in a row, every frame the oracle's"""
     import srz
     monkeypatch.setenv("SRZ_SUB_BATCH", "104")
