@@ -61,6 +61,8 @@ struct srz_ctx {
   bool env_no_packed = false; // SRZ_NO_PACKED (tests): see srz_frameset::no_packed
   bool env_no_turns = false;  // SRZ_NO_TURNS (A/B): renders on different streams do not wait for each other's k_raster
   uint32_t env_clear_wgs = 0; // SRZ_CLEAR_WGS: fixed grid of the side-stream clear (else measured per set, srz_frameset::ClearTune)
+  // what sets of this ctx have measured, by shape (clear_memo_key): a new set of a known shape starts with that grid instead of measuring
+  std::vector<std::pair<uint64_t, uint32_t>> clear_memo;
   bool env_no_clear_tune = false, env_clear_trace = false; // SRZ_CLEAR_TUNE=0: the grid stays at 96; SRZ_CLEAR_TRACE=1: the measurement goes to stderr
   bool opt_approx_shade = false; // SRZ_OPT_APPROX_SHADE (srz_set_option): framesets created from now on shade in the tolerance mode
   bool opt_pool_lazy = false; // SRZ_OPT_POOL_LAZY (srz_set_option; initial value: the environment variable SRZ_POOL_LAZY, read in srz_create)
@@ -154,7 +156,8 @@ struct srz_frameset {
   // of which the device-side state says how many take part, and a one-thread kernel ends each of the next <= 18 renders; the decision
   // arrives in a word of mapped host memory, and from the render that finds it there the host launches exactly that grid.  The pixels are
   // the same bits under every grid.  SRZ_CLEAR_WGS fixes the grid, SRZ_CLEAR_TUNE=0 leaves it at 96, SRZ_CLEAR_TRACE=1 prints the
-  // measurement.  Every CLEAR_TUNE_AGAIN renders the set measures again (the scene of a sceneset changes under it).
+  // measurement.  Every CLEAR_TUNE_AGAIN renders the set measures again (the scene of a sceneset changes under it).  A new set whose shape
+  // another set of the ctx has measured (srz_ctx::clear_memo) starts with that set's grid and measures only then.
   static constexpr int CLEAR_TUNE_SKIP = 6, CLEAR_TUNE_AGAIN = 4096;
   struct ClearTune {
     uint32_t wgs = CLEAR_GRID_DEFAULT; // the grid in use outside the measurement
@@ -526,11 +529,28 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
       *static_cast<volatile uint32_t *>(ct.h_wgs) = 0u; // (no k_clear_tune is in flight: the host stopped launching them when it saw the decision)
       HIP_TRY(ctx, hipMemsetAsync(ct.d_ctl, 0, sizeof(ClearCtl), s));
     }
+    // the shape of the set, as far as the clear's best grid depends on it: frame size, frames, bands, triangles, the shading builds in use
+    auto memo_key = [&]() {
+      uint64_t k = 0xcbf29ce484222325ull;
+      for (uint64_t v : {(uint64_t)fs->width, (uint64_t)fs->height, (uint64_t)fs->n_frames, (uint64_t)fs->n_local_bands, fs->total_tris,
+                         (uint64_t)fs->fast_mask, (uint64_t)fs->approx_shade})
+        k = (k ^ v) * 0x100000001b3ull;
+      return k;
+    };
+    if (!ct.done && ct.renders == 0) // (the set's first render: has a set of this shape measured before?)
+      for (const auto &m : ctx->clear_memo)
+        if (m.first == memo_key()) ct.wgs = clear_wgs = m.second, ct.done = true;
     if (!ct.done) {
       const uint32_t h = *static_cast<volatile uint32_t *>(ct.h_wgs);
       const int j = ct.renders - srz_frameset::CLEAR_TUNE_SKIP;
       if (h != 0u) { // decided: launch that grid from now on
         ct.wgs = clear_wgs = h, ct.done = true;
+        {
+          const uint64_t key = memo_key();
+          auto it = std::find_if(ctx->clear_memo.begin(), ctx->clear_memo.end(), [&](const std::pair<uint64_t, uint32_t> &m) { return m.first == key; });
+          if (it != ctx->clear_memo.end()) it->second = h;
+          else if (ctx->clear_memo.size() < 256) ctx->clear_memo.emplace_back(key, h);
+        }
         if (ctx->env_clear_trace) {
           ClearCtl c;
           if (hipMemcpy(&c, ct.d_ctl, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {

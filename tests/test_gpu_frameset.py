@@ -453,6 +453,15 @@ def test_clear_grid_is_measured_and_every_grid_gives_the_same_bits(orc):
             assert torch.equal(out.view(torch.int32), first.view(torch.int32)), k
     dc = fs.debug_counters()
     assert dc["clear_tuned"] == 1 and dc["clear_wgs"] in (96, 160, 256), dc
+    # a second set of the same shape in the same ctx starts with the grid the first one measured
+    fs2 = ctx.frameset(frames)
+    out.fill_(float("nan"))
+    fs2.render(out.data_ptr(), fs2.out_bytes, abi.FUSED_CLEAR, s)
+    torch.cuda.synchronize()
+    dc2 = fs2.debug_counters()
+    assert dc2["clear_tuned"] == 1 and dc2["clear_wgs"] == dc["clear_wgs"], (dc, dc2)
+    assert torch.equal(out.view(torch.int32), first.view(torch.int32))
+    fs2.close()
     # ... and again 4096 renders later (18 renders, no synchronisation in between): still the same bits, and a grid once more
     for k in range(4096 + 20):
         fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
