@@ -191,7 +191,8 @@ struct RenderArgs {
 // The grid of the side-stream clear is MEASURED per frameset, on the device (srz_api.hip, srz_frameset::ClearTune; k_clear_tune): while a
 // set measures, k_clear is launched with CLEAR_GRID_MAX workgroups of which the first ClearCtl::wgs take part, and a one-thread kernel at
 // the end of every render reads the wall clock, files the time since the previous render's end under the grid in use and moves on —
-// candidates a b c in blocks of CLEAR_TUNE_BLOCK renders (the first sample of a block, the previous grid's tail, is dropped); a grid tried
+// candidates a b c (ascending) in blocks of CLEAR_TUNE_BLOCK renders (the first sample of a block, the previous grid's tail, is dropped;
+// a grid more than 5 % behind the best smaller one ends this pass: the larger ones would only be worse and are not tried); a grid tried
 // after the best of them and more than 5 % behind it is dropped, the others go round once more in the mirrored order c b a (the first
 // renders after idle run up to 10 % slower: the mirror takes a linear ramp out of the comparison, and the ramp is why an EARLIER grid is
 // never dropped on the first pass), the smallest median of the four samples wins.  No host synchronisation, no event query: the

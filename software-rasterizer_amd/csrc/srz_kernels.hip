@@ -2972,19 +2972,29 @@ __global__ void k_clear_tune(ClearCtl *c, uint32_t *h_wgs) {
   c->pos = 0; // a block has ended
   int next = -1;
   if (c->phase == 0u) {
-    if (c->cur + 1u < (uint32_t)CLEAR_CANDS) next = (int)c->cur + 1;
+    // A larger grid that is already more than 5 % behind the best smaller one ends the first pass: the step is the clear, and the grids
+    // beyond it would only be worse (config 2: 96 / 160 / 256 workgroups take 0.78 / 0.88 / 1.04 ms) — they are not tried.
+    bool worse = false;
+    if (c->cur > 0u) {
+      float best = 3.0e38f;
+      for (uint32_t i = 0; i < c->cur; ++i) best = fminf(best, 0.5f * (c->t[i][0] + c->t[i][1]));
+      worse = 0.5f * (c->t[c->cur][0] + c->t[c->cur][1]) > 1.05f * best;
+    }
+    const int tried = (int)c->cur + 1;
+    if (tried < CLEAR_CANDS && !worse) next = tried;
     else { // the first pass is over: who stays?
       // Dropped: a grid that was tried AFTER the best one and is still more than 5 % behind it.  (The first renders after idle, or into
       // buffers touched for the first time, run slower: the first pass favours the later grids, so an earlier one that looks worse
       // stays in, and the mirrored pass settles it.)
       float m[CLEAR_CANDS];
       int ib = 0;
-      for (int i = 0; i < CLEAR_CANDS; ++i) {
+      for (int i = 0; i < tried; ++i) {
         m[i] = 0.5f * (c->t[i][0] + c->t[i][1]);
         if (m[i] < m[ib]) ib = i;
       }
+      for (int i = tried; i < CLEAR_CANDS; ++i) m[i] = 0.f;
       uint32_t alive = 0;
-      for (int i = 0; i < CLEAR_CANDS; ++i)
+      for (int i = 0; i < tried; ++i)
         if (i <= ib || m[i] <= 1.05f * m[ib]) alive |= 1u << i;
       c->alive = alive, c->phase = 1u;
       for (int i = 0; i < CLEAR_CANDS; ++i) c->score[i] = (alive >> i & 1u) ? m[i] : 0.f;

@@ -346,13 +346,16 @@ def test_tight_rectangles_in_the_throughput_build(ctx, orc):
         same(got[i], ref, f"batch frame {i}")
 
 
-@pytest.mark.parametrize("rank,world", [(0, 1), (1, 3)])
-def test_side_stream_clear_odd_width_ragged_height(orc, rank, world):
+@pytest.mark.parametrize("rank,world,grid", [(0, 1, None), (1, 3, None), (0, 1, "37"), (0, 1, "256"), (2, 3, "160")])
+def test_side_stream_clear_odd_width_ragged_height(orc, monkeypatch, rank, world, grid):
     """k_clear on its side stream (sets of >= 8192 tiles) on frames whose width is no multiple of 4 (scalar stores, the last quad cut
     by the frame's edge) and whose height is no multiple of 32 (a ragged last band), most tiles untouched, the buffer poisoned with
-    NaN before every render — unsharded and as rank 1 of 3 (bands dealt by band_of; the shard's rows against the oracle's); rendered
-    often enough that every candidate grid of the clear has been in use"""
+    NaN before every render — unsharded and as a rank of 3 (bands dealt by band_of; the shard's rows against the oracle's); with the
+    grid measured by the set (rendered often enough for that) and with fixed grids (SRZ_CLEAR_WGS, read when the ctx is created:
+    the measurement does not try a larger grid once one is clearly behind)"""
     import srz
+    if grid:
+        monkeypatch.setenv("SRZ_CLEAR_WGS", grid)
     from srz import parallel
     w, h = 333, 301   # 11 x 10 tiles
     n_frames = 84 if world == 1 else 252
@@ -374,7 +377,8 @@ def test_side_stream_clear_odd_width_ragged_height(orc, rank, world):
                 for (lb, b, r0, r1) in rows:
                     a_ = got[i][:, lb * 32: lb * 32 + (r1 - r0)].view(np.uint32)
                     assert np.array_equal(a_, ref[:, r0:r1].view(np.uint32)), (it, i, b)
-    assert fs.debug_counters()["clear_tuned"] == 1
+    dc = fs.debug_counters()
+    assert (dc["clear_wgs"] == int(grid)) if grid else (dc["clear_tuned"] == 1 and dc["clear_wgs"] in (96, 160, 256)), dc
     fs.close(), c.close()
 
 
