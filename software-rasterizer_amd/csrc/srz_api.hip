@@ -508,12 +508,13 @@ int render_impl(srz_ctx *ctx, srz_frameset *fs, float *d_out, uint32_t flags_or,
   const int n_all = f_count < 0 ? fs->n_frames : f_count;
   int chunk = n_all;
   // The sub-batch size is 256 frames' worth of 1024^2 (≈ 262 k tiles: the measured sweet spot; 192 until round 6), in frames of THIS
-  // set — a rank of an 8-GPU job holds an eighth of every frame and takes 2048 of them at a time; frames so large that fewer than 64
-  // make a sub-batch are left alone (nothing of theirs fits the cache either way).
+  // set — a rank of an 8-GPU job holds an eighth of every frame and takes 2048 of them at a time; frames so large that fewer than 96
+  // make a sub-batch (2048^2 and up) are left alone: nothing of theirs fits the cache either way (config 4, 256 frames, in pieces of
+  // 64 / 128 / 256: 0.425 / 0.422 / 0.422).
   const int sub_env = ctx->env_sub_batch; // (tuning / tests: frames per sub-batch)
   const size_t tiles_per_frame = std::max<size_t>((size_t)fs->n_local_bands * fs->tiles_x, 1);
   const int sub = sub_env > 0 ? sub_env : (int)std::min<size_t>((256u * 1024u / tiles_per_frame + 7u) / 8u * 8u, 1u << 20);
-  if (sub >= 64 && n_all >= sub + sub / 4 && !stats && !detailed) {
+  if (sub >= 96 && n_all >= sub + sub / 4 && !stats && !detailed) {
     const int parts = (n_all + sub - 1) / sub;
     chunk = ((n_all + parts - 1) / parts + 7) / 8 * 8;
   }
