@@ -4,6 +4,8 @@ k_raster resolves visibility ORDER-INDEPENDENTLY (one 64-bit depth | tie-break k
 cannot express — a NaN depth that passes a scalar-tail test, a final depth of ±0, a band whose records did not fit the
 pool — is handed to k_raster_slow, the reference's ordered triangle walk (src/Rasterizer.cpp:199-236).  Both must give
 the oracle's framebuffer bit for bit; SRZ_ORDERED_RASTER forces the ordered one everywhere."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -379,6 +381,48 @@ def test_side_stream_clear_odd_width_ragged_height(orc, monkeypatch, rank, world
                     assert np.array_equal(a_, ref[:, r0:r1].view(np.uint32)), (it, i, b)
     dc = fs.debug_counters()
     assert (dc["clear_wgs"] == int(grid)) if grid else (dc["clear_tuned"] == 1 and dc["clear_wgs"] in (96, 160, 256)), dc
+    fs.close(), c.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_side_stream_clear_random_shapes(orc, seed):
+    """the same for seeded random frame shapes (33 .. 700 pixels each way, whatever that makes of quads, tile columns and last bands),
+    as many frames as make 8192 tiles, a random rank of a random world, the grid measured or fixed at random"""
+    import srz
+    from srz import parallel
+    rng = np.random.default_rng(7000 + seed)
+    w, h = int(rng.integers(33, 701)), int(rng.integers(33, 701))
+    world = int(rng.integers(1, 5))
+    rank = int(rng.integers(0, world))
+    tiles = ((w + 31) // 32) * len(parallel.band_rows(h, rank, world))
+    n_frames = -(-8200 // max(tiles, 1))
+    uniq = [frame(adversarial_tris(5000 + 10 * seed + i, int(rng.integers(1, 30)), w, h), w, h, shader=abi.SHADER_NORMAL, flags=abi.FUSED_CLEAR)
+            for i in range(6)]
+    refs = [np.stack(orc.draw(f)[1]) for f in uniq]
+    grid = [None, "64", "200", None, "17", None][seed]
+    if grid:
+        os.environ["SRZ_CLEAR_WGS"] = grid
+    try:
+        c = srz.Context(0, rank, world)
+    finally:
+        os.environ.pop("SRZ_CLEAR_WGS", None)
+    fs = c.frameset([uniq[i % 6] for i in range(n_frames)])
+    out = torch.empty(fs.out_shape, dtype=torch.float32, device="cuda")
+    rows = parallel.band_rows(h, rank, world)
+    s = torch.cuda.current_stream().cuda_stream
+    for it in range(26 if grid is None else 2):
+        out.fill_(float("nan"))
+        fs.render(out.data_ptr(), fs.out_bytes, abi.FUSED_CLEAR, s)
+        torch.cuda.synchronize()
+        if it in (0, 1, 7, 10, 13, 25):
+            got = out.cpu().numpy()
+            for i in sorted({0, 3, 5, n_frames // 2, n_frames - 1}):
+                ref = refs[i % 6]
+                for (lb, b, r0, r1) in rows:
+                    a_ = got[i][:, lb * 32: lb * 32 + (r1 - r0)].view(np.uint32)
+                    assert np.array_equal(a_, ref[:, r0:r1].view(np.uint32)), (seed, w, h, rank, world, it, i, b)
+    dc = fs.debug_counters()   # (a measured grid proves the set is large enough for the side-stream clear: smaller sets never measure)
+    assert (dc["clear_wgs"] == int(grid)) if grid else (dc["clear_tuned"] == 1), (dc, w, h, rank, world, n_frames)
     fs.close(), c.close()
 
 
