@@ -198,7 +198,7 @@ struct RenderArgs {
 // never dropped on the first pass), the smallest median of the four samples wins.  No host synchronisation, no event query: the
 // decision takes effect with the next render whatever the host's run-ahead, and reaches the host through a word of mapped memory.
 constexpr int CLEAR_CANDS = 3, CLEAR_TUNE_BLOCK = 3, CLEAR_TUNE_RENDERS = 2 * CLEAR_CANDS * CLEAR_TUNE_BLOCK;
-constexpr uint32_t CLEAR_CAND[CLEAR_CANDS] = {96, 160, 256};
+constexpr uint32_t CLEAR_CAND[CLEAR_CANDS] = {96, 128, 256};
 constexpr uint32_t CLEAR_GRID_MAX = 256, CLEAR_GRID_DEFAULT = 96;
 struct ClearCtl {
   uint32_t wgs;                  // workgroups of the NEXT render's clear (0: CLEAR_CAND[0] — the state after a memset)

@@ -2973,7 +2973,7 @@ __global__ void k_clear_tune(ClearCtl *c, uint32_t *h_wgs) {
   int next = -1;
   if (c->phase == 0u) {
     // A larger grid that is already more than 5 % behind the best smaller one ends the first pass: the step is the clear, and the grids
-    // beyond it would only be worse (config 2: 96 / 160 / 256 workgroups take 0.78 / 0.88 / 1.04 ms) — they are not tried.
+    // beyond it would only be worse (config 2: 96 / 128 / 256 workgroups take 0.78 / 0.83 / 1.04 ms) — they are not tried.
     bool worse = false;
     if (c->cur > 0u) {
       float best = 3.0e38f;

@@ -380,7 +380,7 @@ def test_side_stream_clear_odd_width_ragged_height(orc, monkeypatch, rank, world
                     a_ = got[i][:, lb * 32: lb * 32 + (r1 - r0)].view(np.uint32)
                     assert np.array_equal(a_, ref[:, r0:r1].view(np.uint32)), (it, i, b)
     dc = fs.debug_counters()
-    assert (dc["clear_wgs"] == int(grid)) if grid else (dc["clear_tuned"] == 1 and dc["clear_wgs"] in (96, 160, 256)), dc
+    assert (dc["clear_wgs"] == int(grid)) if grid else (dc["clear_tuned"] == 1 and dc["clear_wgs"] in (96, 128, 256)), dc
     fs.close(), c.close()
 
 
