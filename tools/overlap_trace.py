@@ -1,12 +1,14 @@
 """Dev tool: what ran beside what.  Reads a rocprofv3 kernel trace (csv) of a two-lane run and prints, per kernel kind, its
 average duration and the share of that duration during which a kernel of each other kind (any stream) was running too.
-usage: python tools/overlap_trace.py <dir with *kernel_trace.csv> [out.json]"""
+usage: python tools/overlap_trace.py <dir with *kernel_trace.csv> [out.json [from to]]  (from / to: fractions of the launch sequence; default 0.5 1.0)"""
 import csv, glob, json, sys, collections
 
 KINDS = ("k_setup", "k_chunks", "k_bin", "k_raster_slow", "k_raster", "k_clear", "k_shade", "k_vertex")
 
 
 def kind_of(name):
+    if "k_clear_tune" in name:  # (the one-thread kernel that ends a measurement render)
+        return None
     for k in KINDS:
         if k in name:
             if k == "k_shade":
@@ -23,8 +25,9 @@ def main():
         if k:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, r.get("Stream_Id") or r.get("Queue_Id")))
     rows.sort()
-    # keep the second half of the run (the timed region, warm)
-    rows = rows[len(rows) // 2:]
+    # keep the second half of the run (the timed region, warm) — or the fractions of it given as 3rd / 4th argument
+    lo_f, hi_f = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (0.5, 1.0)
+    rows = rows[int(len(rows) * lo_f):int(len(rows) * hi_f)]
     dur = collections.defaultdict(float)
     cnt = collections.Counter()
     ov = collections.defaultdict(lambda: collections.defaultdict(float))
